@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-substeps/s of the SPH substep hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one DispatchCompute (ClearGrid -> BuildGrid -> SPHFluid -> OBBConstraints, the
+call of SPHFluid3D.cpp:431-522) over the whole particle set, inputs resident in HBM.
+N = 1 runs BASELINE.json configs[2] (4 194 304 particles, 128^3 grid, fp32), the
+configuration the metric is quoted on.  N > 1 runs the same per-GPU load weak-scaled along z
+(each rank owns a 128 x 128 x 128-cell slab with 4 194 304 particles; one-deep halo exchange
+per substep) -- see DESIGN.md "Multi-GPU".  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "componentframeworks-smoothed-particle-hydrodynamics_amd"
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
+    ap.add_argument("--neighbor", type=int, default=0, help="0 LDS-tiled (default), 1 global gather")
+    ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="substeps of the CPU sample (0 = auto, about 10-30 s)")
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed pass with per-kernel hipEvents")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, rec, sp, cpu_steps):
+    """The oracle (OpenMP port of the same shader math) timed on this host's cores, on the
+    same particle set; the sample is a reduced number of substeps of the same workload."""
+    from oracle import oracle as o
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import to_oracle_params
+    op = to_oracle_params(o, sp)
+    threads = o.max_threads()
+    import numpy as np
+    import ctypes as C
+    cur = rec.copy()
+    scratch = np.zeros_like(cur)
+    L = o.lib()
+
+    def run(k):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            L.sph_oracle_substep(cur.ctypes.data_as(C.c_void_p), scratch.ctypes.data_as(C.c_void_p), len(cur), C.byref(op), -1.0)
+        return time.perf_counter() - t0
+
+    t1 = run(1)                                   # also first-touch / grid warm-up
+    k = cpu_steps if cpu_steps > 0 else max(1, min(50, int(15.0 / max(t1, 1e-3))))
+    t = run(k)
+    return {
+        "value": len(rec) * k / t, "unit": "particle-substeps/s", "cores": threads, "kind": "port",
+        "sample": f"{k} substeps of the same {len(rec)}-particle workload (after 1 warm-up substep), oracle/sph_oracle.c with OpenMP, {t:.2f} s",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    pkg = importlib.import_module(PKG)
+    syn = pkg.synthetic
+
+    if args.gpus > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from importlib import import_module
+        halo = import_module(PKG + ".halo")
+    else:
+        dist = None
+
+    wl = args.workload
+    if wl == "auto":
+        wl = "config3"
+    if wl == "config2":
+        base = syn.CONFIGS[2]
+    elif wl == "config3":
+        base = syn.CONFIGS[3]
+    elif wl == "weak5":
+        base = syn.weak_config(1)
+    else:
+        raise SystemExit(f"unknown workload {wl}")
+    gx, gy, gz = base.grid
+    cfg = syn.BenchConfig(base.index, base.name, base.n * args.gpus, (gx, gy, gz * args.gpus), base.spacing_factor, args.gpus)
+    sp = pkg.default_params(**syn.params_fields(cfg))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if args.gpus == 1:
+        rec, _ = syn.make_particles(cfg)
+        sim = pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream)
+        n_local, n_total = len(rec), len(rec)
+    else:
+        sim = halo.SlabSimulation.from_config(cfg, sp, rank, world, stream=stream)
+        rec = None
+        n_local, n_total = sim.num_owned(), cfg.n
+    sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
+    sim.set_option(pkg.SPH_OPT_AOS_MODE, 0 if args.aos == "eager" else 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dt = -1.0
+    for _ in range(args.warmup):
+        sim.DispatchCompute(dt)
+    sim.set_option(pkg.SPH_OPT_TIMING, 2)          # hipEvents around the dominant kernel only
+    sim.kernel_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.DispatchCompute(dt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = sim.kernel_times(reset=True)
+    sim.set_option(pkg.SPH_OPT_TIMING, 0)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    breakdown = None
+    if args.breakdown or True:
+        sim.set_option(pkg.SPH_OPT_TIMING, 1)
+        sim.kernel_times(reset=True)
+        nb = min(args.steps, 20)
+        for _ in range(nb):
+            sim.DispatchCompute(dt)
+        bt = sim.kernel_times(reset=True)
+        sim.set_option(pkg.SPH_OPT_TIMING, 0)
+        breakdown = {k: round(ms / nb * 1e3, 2) for k, (ms, cnt) in bt.items() if cnt}
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    g = sim.ComputeGridExtents() if args.gpus == 1 else sim.local_grid()
+    C_local = int(g.numCells) if args.gpus == 1 else int(g["numCells"])
+    sph_ms, sph_launches = kt["sph"]
+    sph_avg_s = (sph_ms / max(sph_launches, 1)) * 1e-3
+    alg_bytes = 164 * n_local + 4 * C_local          # SPHFluid pass, per launch
+    achieved = alg_bytes / sph_avg_s / 1e9 if sph_avg_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == wl and tj.get("neighbor") == args.neighbor:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-substeps/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{wl}: {base.n} particles and a {gx}x{gy}x{gz}-cell grid per GPU (BASELINE.json configs[{base.index - 1}]"
+                        + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")",
+            "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
+            "neighbor_kernel": "lds_tile" if args.neighbor == 0 else "global_gather", "aos": args.aos,
+            "pipeline": "bin+scan+scatter+rank -> sph(27-cell, OBB fused) -> AoS write-back" + (" + halo exchange" if args.gpus > 1 else ""),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "k_sph_tile" if args.neighbor == 0 else "k_sph_gather",
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
+            "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
+        },
+        "kernels_us_per_substep": breakdown,
+    }
+    if not args.no_cpu_baseline and args.gpus == 1:
+        out["cpu_baseline"] = cpu_baseline(pkg, rec, sp, args.cpu_steps)
+    elif not args.no_cpu_baseline:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,13 @@
+"""MI355X-native SPH substep engine behind the reference's SPHFluidGPU surface.
+
+Only the hot path SURVEY.md section 8 names lives here: csrc/ (HIP kernels + C-ABI,
+include/sph_abi.h), engine.py (host mirror of the reference class), synthetic.py (bench
+inputs), halo.py (z-slab decomposition).  Import with
+importlib.import_module("componentframeworks-smoothed-particle-hydrodynamics_amd").
+"""
+from .engine import (  # noqa: F401
+    ABI_SYMBOLS, KERNEL_CLASSES, PARTICLE_DTYPE, SPH_OPT_AOS_MODE, SPH_OPT_DEBUG, SPH_OPT_GRID_BUILD,
+    SPH_OPT_NEIGHBOR_KERNEL, SPH_OPT_TIMING, SPHFluidGPU, SphError, SphGridInfo, SphParams,
+    compute_grid_extents, default_params, effective_half, load_library, rotation_mat3, spawn_particles,
+)
+from . import build, synthetic  # noqa: F401

@@ -1,0 +1,569 @@
+// sph_engine.hip -- host driver + C-ABI of the MI355X SPH substep engine.
+//
+// Replaces the GL compute dispatch path of SPHFluidGPU
+// (/root/reference/ComponentFramework/SPHFluid3D.cpp:431-522 DispatchCompute, :604-623
+// ApplyWaveImpulse, :713-731 ResetSimulation, :32-83 ctor/dtor) behind include/sph_abi.h.
+// No CPU fallback: every compute entry point fails with SPH_ERR_HIP when HIP does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sph_abi.h"
+#include "sph_host.h"
+#include "sph_kernels.h"
+#include "sph_tile.h"
+
+static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(SPH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return SPH_OK;
+}
+template <class T>
+void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+inline int blocks_for(size_t n, int per = sph::kBlock) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+struct SphEngine {
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    SphParams params{};
+    SphGridInfo grid{};
+    size_t n = 0;
+    size_t cap = 0;
+    int allocatedCells = 0;
+    uint32_t idBase = 0;
+
+    // options
+    int optNeighbor = 0, optGridBuild = 0, optAos = 0, optTiming = 0;
+
+    // public contract buffer
+    SphParticle* d_aos = nullptr;
+    // internal sorted SoA state, double buffered
+    float4* d_pos[2] = {nullptr, nullptr};
+    float4* d_vel[2] = {nullptr, nullptr};
+    float2* d_rp[2] = {nullptr, nullptr};
+    float* d_foam[2] = {nullptr, nullptr};
+    float4* d_acc = nullptr;
+    int cur = 0;
+    bool internalValid = false, aosValid = false, accValid = false;
+    // grid / sort scratch
+    uint32_t *d_cellOf = nullptr, *d_slotOf = nullptr, *d_order = nullptr;
+    uint2* d_tmp = nullptr;
+    uint32_t *d_cellCount = nullptr, *d_cellStart = nullptr, *d_blockSums = nullptr;
+    int32_t* d_dbg = nullptr;
+    size_t dbgCap = 0;
+    // tile scheduler scratch (sph_tile.h)
+    sph::TilePlan tile{};
+
+    std::vector<SphParticle> hostInit;   // SPHFluidGPU::particles: initial state only
+
+    // timing
+    struct Ev { int cls; hipEvent_t a, b; };
+    std::vector<Ev> evLive;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
+    double kms[SPH_K_COUNT] = {0};
+    int64_t klaunch[SPH_K_COUNT] = {0};
+};
+
+namespace {
+
+using namespace sph;
+
+int flush_events(SphEngine* e) {
+    if (e->evLive.empty()) return SPH_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (auto& ev : e->evLive) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        e->kms[ev.cls] += ms;
+        e->klaunch[ev.cls] += 1;
+        e->evPool.emplace_back(ev.a, ev.b);
+    }
+    e->evLive.clear();
+    return SPH_OK;
+}
+
+struct Timed {   // RAII-ish bracket around one kernel launch when SPH_OPT_TIMING is on
+    SphEngine* e;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(SphEngine* e_, int cls_) : e(e_), cls(cls_) {
+        if (!e->optTiming || (e->optTiming == 2 && cls != SPH_K_SPH)) return;
+        if (e->evPool.empty()) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        } else {
+            a = e->evPool.back().first; b = e->evPool.back().second; e->evPool.pop_back();
+        }
+        (void)hipEventRecord(a, e->stream);
+    }
+    ~Timed() {
+        if (!a) return;
+        (void)hipEventRecord(b, e->stream);
+        e->evLive.push_back({cls, a, b});
+        if (e->evLive.size() >= 8192) (void)flush_events(e);
+    }
+};
+
+void free_particle_buffers(SphEngine* e) {
+    dev_free(e->d_aos);
+    for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
+    dev_free(e->d_acc);
+    dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
+    e->cap = 0;
+}
+void free_grid_buffers(SphEngine* e) {
+    dev_free(e->d_cellCount); dev_free(e->d_cellStart); dev_free(e->d_blockSums);
+    tile_free(e->tile);
+    e->allocatedCells = 0;
+}
+
+int alloc_particle_buffers(SphEngine* e, size_t n) {
+    free_particle_buffers(e);
+    int rc;
+    if ((rc = dev_alloc(&e->d_aos, n))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = dev_alloc(&e->d_pos[b], n))) return rc;
+        if ((rc = dev_alloc(&e->d_vel[b], n))) return rc;
+        if ((rc = dev_alloc(&e->d_rp[b], n))) return rc;
+        if ((rc = dev_alloc(&e->d_foam[b], n))) return rc;
+    }
+    if ((rc = dev_alloc(&e->d_acc, n))) return rc;
+    if ((rc = dev_alloc(&e->d_cellOf, n))) return rc;
+    if ((rc = dev_alloc(&e->d_slotOf, n))) return rc;
+    if ((rc = dev_alloc(&e->d_order, n))) return rc;
+    if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
+    e->cap = n;
+    return SPH_OK;
+}
+
+// cellHead realloc of SPHFluid3D.cpp:440-447 (only when the cell count changed)
+int ensure_grid_buffers(SphEngine* e) {
+    if (e->grid.numCells == e->allocatedCells && e->d_cellCount) return SPH_OK;
+    free_grid_buffers(e);
+    const size_t C = (size_t)e->grid.numCells;
+    int rc;
+    if ((rc = dev_alloc(&e->d_cellCount, C))) return rc;
+    if ((rc = dev_alloc(&e->d_cellStart, C + 1))) return rc;
+    if ((rc = dev_alloc(&e->d_blockSums, (size_t)blocks_for(C, kScanTile) + 1))) return rc;
+    HIP_TRY(hipMemsetAsync(e->d_cellCount, 0, C * sizeof(uint32_t), e->stream));
+    e->allocatedCells = e->grid.numCells;
+    return SPH_OK;
+}
+
+int validate_params(const SphParams& p) {
+    if (!(p.param_h > 0.0f)) return fail(SPH_ERR_ARG, "param_h must be > 0");
+    if (p.param_shapeType >= 7 && p.param_shapeType <= 14)
+        return fail(SPH_ERR_ARG, "param_shapeType %d (OBBConstraints.comp:144-296) is not implemented yet", p.param_shapeType);
+    return SPH_OK;
+}
+
+int set_particles(SphEngine* e, const SphParticle* host, size_t n) {
+    int rc;
+    if (n > e->cap || !e->d_aos) { if ((rc = alloc_particle_buffers(e, n))) return rc; }
+    e->n = n;
+    e->hostInit.assign(host, host + n);
+    if (n) HIP_TRY(hipMemcpyAsync(e->d_aos, host, n * sizeof(SphParticle), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));   // `host` may be a temporary of the caller
+    e->aosValid = true; e->internalValid = false; e->accValid = false; e->cur = 0;
+    return SPH_OK;
+}
+
+int import_state(SphEngine* e) {
+    if (e->internalValid) return SPH_OK;
+    if (!e->aosValid) return fail(SPH_ERR_STATE, "neither the AoS nor the internal state is valid");
+    if (e->n) {
+        Timed t(e, SPH_K_OTHER);
+        hipLaunchKernelGGL(k_import, dim3(blocks_for(e->n)), dim3(kBlock), 0, e->stream, e->d_aos, e->d_pos[e->cur],
+                           e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->idBase, (int)e->n);
+    }
+    HIP_TRY(hipGetLastError());
+    e->internalValid = true;
+    e->accValid = false;
+    return SPH_OK;
+}
+
+// ClearGrid + BuildGrid as a counting sort: after this, d_cellStart/d_order describe the
+// current state buffer.
+int build_grid(SphEngine* e, const SimK& k) {
+    const int n = (int)e->n, C = e->grid.numCells;
+    const int nb = blocks_for(n), sb = blocks_for((size_t)C, kScanTile);
+    if (n) {
+        Timed t(e, SPH_K_BIN);
+        hipLaunchKernelGGL(k_bin, dim3(nb), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellCount, n);
+    }
+    {
+        Timed t(e, SPH_K_SCAN);
+        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, C);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kBlock), 0, e->stream, e->d_blockSums, sb);
+        hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, e->d_cellStart, C, (uint32_t)n);
+    }
+    if (n) {
+        Timed t(e, SPH_K_SCATTER);
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n);
+        hipLaunchKernelGGL(k_rank, dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
+int writeback(SphEngine* e) {
+    if (e->aosValid) return SPH_OK;
+    if (!e->internalValid) return fail(SPH_ERR_STATE, "no valid particle state");
+    if (!e->accValid) return fail(SPH_ERR_STATE, "internal acc buffer is stale");
+    if (e->n) {
+        Timed t(e, SPH_K_WRITEBACK);
+        hipLaunchKernelGGL(k_writeback, dim3(blocks_for(e->n)), dim3(kBlock), 0, e->stream, e->d_aos, e->d_pos[e->cur], e->d_vel[e->cur],
+                           e->d_rp[e->cur], e->d_foam[e->cur], e->d_acc, e->idBase, (int)e->n);
+    }
+    HIP_TRY(hipGetLastError());
+    e->aosValid = true;
+    return SPH_OK;
+}
+
+int dispatch_one(SphEngine* e, float overrideDt) {
+    if (e->params.param_pause) return SPH_OK;                               // SPHFluid3D.cpp:432
+    int rc;
+    if ((rc = validate_params(e->params))) return rc;
+    const float dt = overrideDt > 0.0f ? overrideDt : e->params.param_timeStep;   // :434
+    compute_grid_extents(e->params, e->grid);                               // :439
+    if ((rc = ensure_grid_buffers(e))) return rc;                           // :440-447
+    SimK k;
+    make_simk(e->params, e->grid, dt, k);
+    if ((rc = import_state(e))) return rc;
+    if ((rc = build_grid(e, k))) return rc;                                 // :449-468
+    const int n = (int)e->n;
+    StateIn in{e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur]};
+    const int nx = e->cur ^ 1;
+    StateOut out{e->d_pos[nx], e->d_vel[nx], e->d_rp[nx], e->d_foam[nx], e->d_acc};
+    if (n) {                                                                // :470-509 (SPH + OBB fused)
+        if (e->optNeighbor == 1) {
+            Timed t(e, SPH_K_SPH);
+            hipLaunchKernelGGL(k_sph_gather, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, e->d_order, e->d_cellStart, n);
+        } else {
+            if ((rc = tile_launch(e->tile, e->stream, k, in, out, e->d_order, e->d_cellStart, n, [&](int cls) { return Timed(e, cls); }))) {
+                return fail(SPH_ERR_HIP, "tiled SPH pass failed: %s", hipGetErrorString((hipError_t)(-rc)));
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    e->cur = nx;
+    e->accValid = true;
+    e->aosValid = false;
+    if (e->optAos == 0) return writeback(e);
+    return SPH_OK;
+}
+
+}  // namespace
+
+// ======================================================================== C-ABI
+extern "C" {
+
+int sph_abi_version(void) { return SPH_ABI_VERSION; }
+const char* sph_last_error(void) { return g_err.c_str(); }
+
+int sph_params_default(SphParams* out) {
+    if (!out) return fail(SPH_ERR_ARG, "null params");
+    sph::params_default(*out);
+    return SPH_OK;
+}
+int sph_rotation_mat3(const float eulerDeg[3], float outM[9]) {
+    if (!eulerDeg || !outM) return fail(SPH_ERR_ARG, "null argument");
+    sph::rotation_mat3(eulerDeg, outM);
+    return SPH_OK;
+}
+int sph_effective_half(const SphParams* params, float outHalf[3]) {
+    if (!params || !outHalf) return fail(SPH_ERR_ARG, "null argument");
+    sph::effective_half(*params, outHalf);
+    return SPH_OK;
+}
+int sph_compute_grid_extents(const SphParams* params, SphGridInfo* out) {
+    if (!params || !out) return fail(SPH_ERR_ARG, "null argument");
+    sph::compute_grid_extents(*params, *out);
+    return SPH_OK;
+}
+int sph_spawn_particles(const SphParams* params, size_t nRequested, uint32_t seed, SphParticle* out, size_t* nOut, float* massOut) {
+    if (!params || !out || !nOut || !massOut) return fail(SPH_ERR_ARG, "null argument");
+    std::vector<SphParticle> v;
+    float m;
+    sph::spawn_particles(*params, nRequested, seed, v, m);
+    std::memcpy(out, v.data(), v.size() * sizeof(SphParticle));
+    *nOut = v.size();
+    *massOut = m;
+    return SPH_OK;
+}
+
+static int create_common(SphEngine** out, const SphParams* params, void* stream, SphEngine** made) {
+    if (!out || !params) return fail(SPH_ERR_ARG, "null argument");
+    *out = nullptr;
+    int rc;
+    if ((rc = validate_params(*params))) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(SPH_ERR_HIP, "no HIP device: this engine has no CPU fallback");
+    SphEngine* e = new SphEngine();
+    e->params = *params;
+    if (stream) { e->stream = (hipStream_t)stream; e->ownStream = false; }
+    else {
+        hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (er != hipSuccess) { delete e; return fail(SPH_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(er)); }
+        e->ownStream = true;
+    }
+    *made = e;
+    return SPH_OK;
+}
+
+int sph_create(SphEngine** out, size_t nRequested, const SphParams* params, uint32_t seed, void* stream) {
+    SphEngine* e = nullptr;
+    int rc = create_common(out, params, stream, &e);
+    if (rc) return rc;
+    std::vector<SphParticle> v;
+    float m;
+    sph::spawn_particles(e->params, nRequested, seed, v, m);          // SPHFluid3D.cpp:50
+    e->params.param_mass = m;                                         // :92
+    sph::compute_grid_extents(e->params, e->grid);                    // :53
+    if ((rc = set_particles(e, v.data(), v.size())) || (rc = ensure_grid_buffers(e))) { sph_destroy(e); return rc; }
+    *out = e;
+    return SPH_OK;
+}
+
+int sph_create_from_particles(SphEngine** out, const SphParticle* particles, size_t n, const SphParams* params, void* stream) {
+    if (!particles && n) return fail(SPH_ERR_ARG, "null particles");
+    SphEngine* e = nullptr;
+    int rc = create_common(out, params, stream, &e);
+    if (rc) return rc;
+    sph::compute_grid_extents(e->params, e->grid);
+    if ((rc = set_particles(e, particles, n)) || (rc = ensure_grid_buffers(e))) { sph_destroy(e); return rc; }
+    *out = e;
+    return SPH_OK;
+}
+
+int sph_destroy(SphEngine* e) {
+    if (!e) return SPH_OK;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    free_particle_buffers(e);
+    free_grid_buffers(e);
+    dev_free(e->d_dbg);
+    for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return SPH_OK;
+}
+
+int sph_reset(SphEngine* e, size_t nRequested, uint32_t seed) {       // SPHFluid3D.cpp:713-731
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    int rc;
+    if ((rc = validate_params(e->params))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<SphParticle> v;
+    float m;
+    sph::spawn_particles(e->params, nRequested, seed, v, m);
+    e->params.param_mass = m;
+    sph::compute_grid_extents(e->params, e->grid);
+    free_particle_buffers(e);                                         // :714-719 delete + recreate
+    if ((rc = set_particles(e, v.data(), v.size()))) return rc;
+    return ensure_grid_buffers(e);
+}
+
+int sph_set_params(SphEngine* e, const SphParams* params) {
+    if (!e || !params) return fail(SPH_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = validate_params(*params))) return rc;
+    e->params = *params;
+    return SPH_OK;
+}
+int sph_get_params(const SphEngine* e, SphParams* out) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    *out = e->params;
+    return SPH_OK;
+}
+int sph_set_option(SphEngine* e, int option, int value) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    switch (option) {
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optNeighbor = value; break;
+    case SPH_OPT_GRID_BUILD: if (value != 0) return fail(SPH_ERR_ARG, "linked-list grid build not implemented yet"); e->optGridBuild = value; break;
+    case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
+    case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
+    case SPH_OPT_DEBUG: e->tile.debugFlags = value; break;
+    case SPH_OPT_TILE_X: case SPH_OPT_TILE_Y: case SPH_OPT_TILE_Z: {
+        int tx = e->tile.tx, ty = e->tile.ty, tz = e->tile.tz;
+        (option == SPH_OPT_TILE_X ? tx : option == SPH_OPT_TILE_Y ? ty : tz) = value;
+        if (value < 1 || (ty + 2) * (tz + 2) > sph::kMaxRows || (tx + 2) * (ty + 2) * (tz + 2) > sph::kMaxHaloCells)
+            return fail(SPH_ERR_ARG, "tile %dx%dx%d exceeds the kernel's LDS tables", tx, ty, tz);
+        e->tile.tx = tx; e->tile.ty = ty; e->tile.tz = tz;
+        break;
+    }
+    default: return fail(SPH_ERR_ARG, "unknown option %d", option);
+    }
+    return SPH_OK;
+}
+int sph_get_option(const SphEngine* e, int option, int* value) {
+    if (!e || !value) return fail(SPH_ERR_ARG, "null argument");
+    switch (option) {
+    case SPH_OPT_NEIGHBOR_KERNEL: *value = e->optNeighbor; break;
+    case SPH_OPT_GRID_BUILD: *value = e->optGridBuild; break;
+    case SPH_OPT_AOS_MODE: *value = e->optAos; break;
+    case SPH_OPT_TIMING: *value = e->optTiming; break;
+    case SPH_OPT_DEBUG: *value = e->tile.debugFlags; break;
+    case SPH_OPT_TILE_X: *value = e->tile.tx; break;
+    case SPH_OPT_TILE_Y: *value = e->tile.ty; break;
+    case SPH_OPT_TILE_Z: *value = e->tile.tz; break;
+    default: return fail(SPH_ERR_ARG, "unknown option %d", option);
+    }
+    return SPH_OK;
+}
+
+int sph_dispatch(SphEngine* e, float overrideDt) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    return dispatch_one(e, overrideDt);
+}
+int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    for (int i = 0; i < nSubsteps; ++i) {
+        int rc = dispatch_one(e, overrideDt);
+        if (rc) return rc;
+    }
+    return SPH_OK;
+}
+
+int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, float phase, const float dir[3], float yMin, float yMax) {
+    if (!e || !dir) return fail(SPH_ERR_ARG, "null argument");
+    if (amplitude == 0.0f || wavelength <= 1e-6f) return SPH_OK;      // SPHFluid3D.cpp:607
+    int rc;
+    if ((rc = import_state(e))) return rc;
+    WaveK w;
+    const float len = std::sqrt(std::fma(dir[2], dir[2], std::fma(dir[1], dir[1], dir[0] * dir[0])));
+    if (len > 1e-6f) { w.ndx = dir[0] / len; w.ndy = dir[1] / len; w.ndz = dir[2] / len; }   // WaveImpulse.comp:39
+    else { w.ndx = 0.0f; w.ndy = 1.0f; w.ndz = 0.0f; }
+    w.amplitude = amplitude; w.kk = 6.28318530718f / wavelength; w.phase = phase; w.yMin = yMin; w.yMax = yMax;
+    if (e->n) {
+        Timed t(e, SPH_K_IMPULSE);
+        hipLaunchKernelGGL(k_wave_impulse, dim3(blocks_for(e->n)), dim3(kBlock), 0, e->stream, w, e->d_pos[e->cur], e->d_vel[e->cur],
+                           e->aosValid ? e->d_aos : nullptr, e->idBase, (int)e->n);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
+size_t sph_num_particles(const SphEngine* e) { return e ? e->n : 0; }
+
+int sph_grid_info(const SphEngine* e, SphGridInfo* out) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    *out = e->grid;
+    return SPH_OK;
+}
+
+int sph_upload_particles(SphEngine* e, const SphParticle* host, size_t n) {
+    if (!e || (!host && n)) return fail(SPH_ERR_ARG, "null argument");
+    if (n != e->n) return fail(SPH_ERR_ARG, "upload of %zu records into an engine of %zu particles", n, e->n);
+    if (n) HIP_TRY(hipMemcpyAsync(e->d_aos, host, n * sizeof(SphParticle), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->aosValid = true; e->internalValid = false; e->accValid = false;
+    return SPH_OK;
+}
+
+int sph_download_particles(SphEngine* e, SphParticle* host, size_t n) {
+    if (!e || (!host && n)) return fail(SPH_ERR_ARG, "null argument");
+    if (n != e->n) return fail(SPH_ERR_ARG, "download of %zu records from an engine of %zu particles", n, e->n);
+    int rc;
+    if ((rc = writeback(e))) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(host, e->d_aos, n * sizeof(SphParticle), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SPH_OK;
+}
+
+int sph_device_particles(SphEngine* e, const SphParticle** devPtr) {
+    if (!e || !devPtr) return fail(SPH_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = writeback(e))) return rc;
+    *devPtr = e->d_aos;
+    return SPH_OK;
+}
+
+int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n) {
+    if (!e || (!host && n)) return fail(SPH_ERR_ARG, "null argument");
+    if (n != e->hostInit.size()) return fail(SPH_ERR_ARG, "size mismatch");
+    std::memcpy(host, e->hostInit.data(), n * sizeof(SphParticle));
+    return SPH_OK;
+}
+
+int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* particleCell, size_t n) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    int rc;
+    sph::compute_grid_extents(e->params, e->grid);
+    if ((rc = ensure_grid_buffers(e))) return rc;
+    if (nCells != (size_t)e->grid.numCells || n != e->n) return fail(SPH_ERR_ARG, "size mismatch (cells %d, particles %zu)", e->grid.numCells, e->n);
+    SimK k;
+    make_simk(e->params, e->grid, e->params.param_timeStep, k);
+    if ((rc = import_state(e))) return rc;
+    if ((rc = build_grid(e, k))) return rc;
+    const size_t need = std::max(nCells, n);
+    if (need > e->dbgCap) { dev_free(e->d_dbg); if ((rc = dev_alloc(&e->d_dbg, need))) return rc; e->dbgCap = need; }
+    if (cellCount) {
+        hipLaunchKernelGGL(k_debug_cells, dim3(blocks_for(nCells)), dim3(kBlock), 0, e->stream, e->d_cellStart, e->d_dbg, (int)nCells);
+        HIP_TRY(hipMemcpyAsync(cellCount, e->d_dbg, nCells * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    if (particleCell && n) {
+        hipLaunchKernelGGL(k_debug_particle_cell, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_vel[e->cur], e->d_dbg, e->idBase, (int)n);
+        HIP_TRY(hipMemcpyAsync(particleCell, e->d_dbg, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_sync(SphEngine* e) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SPH_OK;
+}
+
+int sph_kernel_times(SphEngine* e, double msOut[SPH_K_COUNT], int64_t launchesOut[SPH_K_COUNT], int reset) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    int rc;
+    if ((rc = flush_events(e))) return rc;
+    for (int i = 0; i < SPH_K_COUNT; ++i) {
+        if (msOut) msOut[i] = e->kms[i];
+        if (launchesOut) launchesOut[i] = e->klaunch[i];
+        if (reset) { e->kms[i] = 0.0; e->klaunch[i] = 0; }
+    }
+    return SPH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// sph_host.h -- host-side scalar logic of SPHFluidGPU that needs no device:
+// defaults, MakeRotationMat3XYZ, EffectiveHalf, ComputeGridExtents, the standard-fill
+// spawn and the per-dispatch constant derivation.  Citations are relative to
+// /root/reference/ComponentFramework.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sph_abi.h"
+#include "sph_device.h"
+
+namespace sph {
+
+inline void params_default(SphParams& p) {            // SPHFluid3D.h:94-124
+    std::memset(&p, 0, sizeof(p));
+    p.param_h = 0.28f;
+    p.param_mass = 13.8f;
+    p.param_restDensity = 1000.0f;
+    p.param_gasConstant = 2000.0f;
+    p.param_viscosity = 3.5f;
+    p.param_gravityY = -980.0f;
+    p.param_gravityX = 0.0f;
+    p.param_gravityZ = 0.0f;
+    p.param_surfaceTension = 0.0728f;
+    p.param_timeStep = 0.001f;
+    p.param_pause = 0;
+    p.param_useJitter = 1;
+    p.param_jitterAmp = 0.20f;
+    p.param_foamGen = 1.0f;
+    p.param_foamVelRef = 8.0f;
+    p.param_boxHalf[0] = p.param_boxHalf[1] = p.param_boxHalf[2] = 7.0f;
+    p.param_shapeType = 0;
+    p.param_shapeAux[0] = 5.0f; p.param_shapeAux[1] = 0.35f; p.param_shapeAux[2] = 2.5f;
+    p.param_wallRestitution = 0.15f;
+    p.param_wallFriction = 0.02f;
+    p.grid_cap = 160;                                  // SPHFluid3D.cpp:370
+}
+
+// SPHFluid3D.cpp:13-30.  outM is column-major world_from_box, R = Rz * Ry * Rx.
+inline void rotation_mat3(const float e[3], float outM[9]) {
+    const float d2r = float(3.14159265358979323846 / 180.0);
+    const float rx = e[0] * d2r, ry = e[1] * d2r, rz = e[2] * d2r;
+    const float cx = std::cos(rx), sx = std::sin(rx);
+    const float cy = std::cos(ry), sy = std::sin(ry);
+    const float cz = std::cos(rz), sz = std::sin(rz);
+    const float Z[9] = {cz, sz, 0, -sz, cz, 0, 0, 0, 1};
+    const float Y[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
+    const float X[9] = {1, 0, 0, 0, cx, sx, 0, -sx, cx};
+    auto mul = [](const float* A, const float* B, float* Cm) {
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r)
+                Cm[c * 3 + r] = A[r] * B[c * 3] + A[3 + r] * B[c * 3 + 1] + A[6 + r] * B[c * 3 + 2];
+    };
+    float ZY[9];
+    mul(Z, Y, ZY);
+    mul(ZY, X, outM);
+}
+
+// SPHFluid3D.h:127-158
+inline void effective_half(const SphParams& p, float o[3]) {
+    const float x = p.param_boxHalf[0], y = p.param_boxHalf[1], z = p.param_boxHalf[2];
+    const float a0 = p.param_shapeAux[0], a1 = p.param_shapeAux[1];
+    switch (p.param_shapeType) {
+    case 1: case 13: o[0] = x; o[1] = x; o[2] = x; return;
+    case 2: case 5: case 6: case 7: case 8: o[0] = x; o[1] = y; o[2] = x; return;
+    case 3: o[0] = x + y; o[1] = y; o[2] = x + y; return;
+    case 4: o[0] = x; o[1] = y + x; o[2] = x; return;
+    case 9: o[0] = 3.0f * x + y; o[1] = 0.35f * x + y; o[2] = 3.0f * x + y; return;
+    case 10: o[0] = x + y; o[1] = y + a0; o[2] = x + y; return;
+    case 11: case 14: o[0] = x + y; o[1] = a1 + y; o[2] = x + y; return;
+    case 12: o[0] = x + y; o[1] = 1.15f * x + y; o[2] = y + 0.3f; return;
+    default: o[0] = x; o[1] = y; o[2] = z; return;
+    }
+}
+
+// SPHFluid3D.cpp:354-376
+inline void compute_grid_extents(const SphParams& p, SphGridInfo& g) {
+    float R[9], half[3];
+    g.cellSize = p.param_h;
+    rotation_mat3(p.param_boxEulerDeg, R);
+    effective_half(p, half);
+    const int cap = p.grid_cap > 0 ? p.grid_cap : 160;
+    for (int i = 0; i < 3; ++i) {
+        float ext = std::fabs(R[i]) * half[0] + std::fabs(R[3 + i]) * half[1] + std::fabs(R[6 + i]) * half[2];
+        ext = ext + g.cellSize;
+        g.gridMin[i] = p.param_boxCenter[i] - ext;
+        int d = int(std::ceil((2.0f * ext) / g.cellSize));
+        g.dims[i] = d < 1 ? 1 : (d > cap ? cap : d);
+    }
+    const long long nc = (long long)g.dims[0] * g.dims[1] * g.dims[2];
+    g.numCells = nc < 1 ? 1 : (int)nc;
+}
+
+// Per-dispatch constants (uniform derivation of SPHFluid3D.cpp:458-506, incl. maxSpeed :488).
+inline void make_simk(const SphParams& p, const SphGridInfo& g, float dt, SimK& k) {
+    const float h = p.param_h;
+    const float h2 = h * h, h3 = h2 * h, h6 = h3 * h3, h9 = h6 * h3;
+    const float pi_f = 3.141592653589f;               // literal of SPHFluid.comp:45,53,60
+    k.h = h; k.h2 = h2;
+    k.poly6C = 315.0f / ((64.0f * pi_f) * h9);
+    k.spikyC = -45.0f / (pi_f * h6);
+    k.viscC = 45.0f / (pi_f * h6);
+    k.mass = p.param_mass; k.negMass = -p.param_mass;
+    k.rho0 = p.param_restDensity; k.halfRho0 = p.param_restDensity * 0.5f;
+    k.kgas = p.param_gasConstant; k.visc = p.param_viscosity; k.negSigma = -p.param_surfaceTension;
+    k.gravx = p.param_gravityX; k.gravy = p.param_gravityY; k.gravz = p.param_gravityZ;
+    k.dt = dt;
+    k.maxSpeed = (0.4f * h) / std::fmax(dt, 1e-6f);
+    k.foamGen = p.param_foamGen;
+    k.foamVelRefMax = std::fmax(p.param_foamVelRef, 1e-3f);
+    k.gminx = g.gridMin[0]; k.gminy = g.gridMin[1]; k.gminz = g.gridMin[2];
+    k.cellSize = g.cellSize;
+    k.gx = g.dims[0]; k.gy = g.dims[1]; k.gz = g.dims[2]; k.numCells = g.numCells;
+    rotation_mat3(p.param_boxEulerDeg, k.R);
+    k.bcx = p.param_boxCenter[0]; k.bcy = p.param_boxCenter[1]; k.bcz = p.param_boxCenter[2];
+    k.bhx = p.param_boxHalf[0]; k.bhy = p.param_boxHalf[1]; k.bhz = p.param_boxHalf[2];
+    k.auxx = p.param_shapeAux[0]; k.auxy = p.param_shapeAux[1]; k.auxz = p.param_shapeAux[2];
+    k.negRest = -p.param_wallRestitution;
+    k.oneMinusFric = 1.0f - p.param_wallFriction;
+    k.shape = p.param_shapeType;
+}
+
+// ---- spawn -------------------------------------------------------------------------
+// PCG32 (XSH-RR) replaces default_random_engine(time(nullptr)) of SPHFluid3D.cpp:99.
+struct Pcg32 {
+    uint64_t state = 0, inc = (54ull << 1) | 1ull;
+    explicit Pcg32(uint64_t seed) { next(); state += seed; next(); }
+    uint32_t next() {
+        const uint64_t old = state;
+        state = old * 6364136223846793005ull + inc;
+        const uint32_t xs = uint32_t(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = uint32_t(old >> 59u);
+        return (xs >> rot) | (xs << ((32u - rot) & 31u));
+    }
+    float uniform(float lo, float hi) { return lo + (float(next() >> 8) * (1.0f / 16777216.0f)) * (hi - lo); }
+};
+
+// insideShape lambda of SPHFluid3D.cpp:167-289 for the shapes the engine implements.
+inline bool inside_shape(const SphParams& p, const float hf[3], float margin, float lx, float ly, float lz) {
+    const float bx = p.param_boxHalf[0], by = p.param_boxHalf[1], bz = p.param_boxHalf[2];
+    switch (p.param_shapeType) {
+    case 1: { const float r = hf[0] - margin; return lx * lx + ly * ly + lz * lz <= r * r; }
+    case 2: { const float r = hf[0] - margin; return lx * lx + lz * lz <= r * r && std::fabs(ly) <= hf[1] - margin; }
+    case 3: { const float r = by - margin; const float dr = std::sqrt(lx * lx + lz * lz) - bx;
+              return r > 0.0f && (dr * dr + ly * ly) <= r * r; }
+    case 4: { const float r = bx - margin; const float cy = std::fmin(std::fmax(ly, -by), by); const float dy = ly - cy;
+              return (lx * lx + lz * lz + dy * dy) <= r * r; }
+    case 5: { const float H = std::fmax(by, 1e-6f), neck = std::fmin(bz, bx);
+              if (std::fabs(ly) > H - margin) return false;
+              const float rMax = neck + (bx - neck) * std::fabs(ly) / H - margin;
+              return rMax > 0.0f && (lx * lx + lz * lz) <= rMax * rMax; }
+    case 6: { const float a = std::fmax(bx - margin, 1e-4f), b = std::fmax(by - margin, 1e-4f);
+              const float u = lx / a, v = ly / b, w = lz / a;
+              return (u * u + v * v + w * w) <= 1.0f; }
+    default: return true;
+    }
+}
+
+// InitializeParticles, standard-fill branch (SPHFluid3D.cpp:85-102,159-332).
+inline void spawn_particles(const SphParams& p, size_t nRequested, uint32_t seed,
+                            std::vector<SphParticle>& out, float& massOut) {
+    const float spacing = p.param_h * 0.85f;                                  // :89
+    massOut = p.param_restDensity * spacing * spacing * spacing;              // :92
+    const float fillFraction = 0.4f;                                          // :97
+    Pcg32 rng(seed);
+    const float jl = -spacing * p.param_jitterAmp, jh = spacing * p.param_jitterAmp;
+    float hf[3];
+    effective_half(p, hf);
+    const float margin = spacing * 0.5f;
+    const int layersY = std::max(1, int((2.0f * hf[1] * fillFraction) / spacing));  // :290-292
+    const int sideX = std::max(1, int((hf[0] * 1.7f) / spacing));
+    const int sideZ = std::max(1, int((hf[2] * 1.7f) / spacing));
+    out.clear();
+    for (int x = 0; x < sideX && out.size() < nRequested; ++x)
+        for (int y = 0; y < layersY && out.size() < nRequested; ++y)
+            for (int z = 0; z < sideZ && out.size() < nRequested; ++z) {
+                const float jx = p.param_useJitter ? rng.uniform(jl, jh) : 0.0f;
+                const float jy = p.param_useJitter ? rng.uniform(jl, jh) : 0.0f;
+                const float jz = p.param_useJitter ? rng.uniform(jl, jh) : 0.0f;
+                const float lx = -hf[0] * 0.85f + float(x) * spacing + jx;    // :296-298
+                const float ly = -hf[1] + spacing + float(y) * spacing + jy;
+                const float lz = -hf[2] * 0.85f + float(z) * spacing + jz;
+                if (!inside_shape(p, hf, margin, lx, ly, lz)) continue;
+                SphParticle q;
+                std::memset(&q, 0, sizeof(q));
+                q.pos[0] = p.param_boxCenter[0] + lx;
+                q.pos[1] = p.param_boxCenter[1] + ly;
+                q.pos[2] = p.param_boxCenter[2] + lz;
+                if (p.param_mixPattern == 1) q.padC = (x + y + z) & 1;        // :307-311
+                else if (p.param_mixPattern == 2) q.padC = int(rng.next() & 1u);
+                else q.padC = (lx < 0.0f) ? 0 : 1;
+                float d;                                                      // :316-329
+                if (p.param_dyePattern == 1) d = (ly + hf[1]) / std::fmax(2.0f * hf[1], 1e-3f);
+                else if (p.param_dyePattern == 2) {
+                    const float nn = std::sin(lx * 1.3f) * std::cos(lz * 1.7f) + std::sin(ly * 1.1f + lx * 0.7f);
+                    d = 0.5f + 0.5f * std::sin(nn * 2.3f);
+                } else d = 0.5f + 0.5f * std::sin(lx * 1.5f);
+                q.padB = std::fmin(std::fmax(d, 0.0f), 1.0f);
+                out.push_back(q);
+            }
+}
+
+}  // namespace sph

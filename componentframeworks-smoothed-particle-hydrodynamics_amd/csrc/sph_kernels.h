@@ -1,0 +1,325 @@
+// sph_kernels.h -- HIP kernels of the substep pipeline (gfx950, wave64).
+//
+// Pipeline of one sph_dispatch() (reference: SPHFluid3D.cpp:431-509):
+//   k_bin      cell index + per-cell histogram      (BuildGrid.comp:21-31, without the list push)
+//   k_scan_*   exclusive scan of the histogram, clears it for the next substep (ClearGrid.comp)
+//   k_scatter  counting-sort scatter into cell-contiguous slots (replaces cellHead/particleNext)
+//   k_rank     canonical order inside a cell: ascending particle id (makes fp32 sums reproducible)
+//   k_sph_*    27-cell density -> pressure -> forces -> integrate -> XSPH -> cap -> foam, with
+//              OBBConstraints.comp fused into the epilogue (legal: neighbours are read from the
+//              entry snapshot, the own record is private to the thread)
+//   k_writeback  update of the public 80-byte AoS in ORIGINAL particle order
+//
+// Internal state ("sorted SoA", double buffered; slot s of substep n's output is the s-th
+// particle in (cell, id) order of substep n):
+//   pos[s] = (x, y, z, flag bits)   vel[s] = (vx, vy, vz, particle id bits)
+//   rp[s]  = (density, pressure)    foam[s] = padA           acc[s] = (ax, ay, az, 0)
+#pragma once
+#include "sph_device.h"
+
+namespace sph {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
+
+// ---- AoS -> internal state (after upload / reset) ------------------------------------
+__global__ __launch_bounds__(kBlock) void k_import(const SphParticle* __restrict__ aos, float4* __restrict__ pos,
+                                                   float4* __restrict__ vel, float2* __restrict__ rp,
+                                                   float* __restrict__ foam, uint32_t idBase, int n) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* rec = reinterpret_cast<const float4*>(aos + i);
+    float4 p = rec[0], v = rec[1], d = rec[3];
+    int4 fl = *reinterpret_cast<const int4*>(rec + 4);
+    uint32_t flags = (fl.x == 1 ? F_GHOST1 : 0u) | (fl.x != 0 ? F_GHOSTNZ : 0u) | (fl.y == 0 ? F_INACTIVE : 0u);
+    pos[i] = make_float4(p.x, p.y, p.z, bitsf(flags));
+    vel[i] = make_float4(v.x, v.y, v.z, bitsf(idBase + (uint32_t)i));
+    rp[i] = make_float2(d.x, d.y);
+    foam[i] = d.z;
+}
+
+// ---- BuildGrid.comp:21-31: cell of every particle + histogram -------------------------
+__global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict__ pos, uint32_t* __restrict__ cellOf,
+                                                uint32_t* __restrict__ slotOf, uint32_t* __restrict__ cellCount, int n) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos[i];
+    int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
+    int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
+    int cz = cell_axis(p.z, k.gminz, k.cellSize, k.gz);
+    uint32_t cell = (uint32_t)((cz * k.gy + cy) * k.gx + cx);   // flatten(), BuildGrid.comp:19
+    cellOf[i] = cell;
+    slotOf[i] = atomicAdd(&cellCount[cell], 1u);
+}
+
+// ---- exclusive scan over the histogram -------------------------------------------------
+constexpr int kScanItems = 16;                       // 256 threads x 16 = 4096 cells per block
+constexpr int kScanTile = kBlock * kScanItems;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns the
+// exclusive prefix and, through total, the block sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sm, uint32_t& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint32_t w0 = sm[0], w1 = sm[1], w2 = sm[2], w3 = sm[3];
+    uint32_t base = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ blockSums, int numCells) {
+    __shared__ uint32_t sm[4];
+    const int base = blockIdx.x * kScanTile;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        int c = base + j * kBlock + threadIdx.x;
+        if (c < numCells) s += cnt[c];
+    }
+    uint32_t total;
+    (void)block_excl_scan(s, sm, total);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the per-block sums (any count, chunks of 256 with carry)
+__global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict__ blockSums, int numBlocks) {
+    __shared__ uint32_t sm[4];
+    uint32_t carry = 0;
+    for (int base = 0; base < numBlocks; base += kBlock) {
+        int i = base + threadIdx.x;
+        uint32_t v = (i < numBlocks) ? blockSums[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, sm, total);
+        if (i < numBlocks) blockSums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// per-block scan + block offset -> cellStart[0..numCells]; clears the histogram (ClearGrid)
+__global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ blockSums,
+                                                       uint32_t* __restrict__ cellStart, int numCells, uint32_t nTotal) {
+    __shared__ uint32_t sm[4];
+    const int base = blockIdx.x * kScanTile;
+    uint32_t carry = blockSums[blockIdx.x];
+#pragma unroll 1
+    for (int j = 0; j < kScanItems; ++j) {
+        int c = base + j * kBlock + threadIdx.x;
+        uint32_t v = (c < numCells) ? cnt[c] : 0u;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, sm, total);
+        if (c < numCells) { cellStart[c] = carry + ex; cnt[c] = 0u; }
+        carry += total;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cellStart[numCells] = nTotal;
+}
+
+// ---- counting-sort scatter: tmp[slot] = (particle id, source index) ---------------------
+__global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ vel, const uint32_t* __restrict__ cellOf,
+                                                    const uint32_t* __restrict__ slotOf, const uint32_t* __restrict__ cellStart,
+                                                    uint2* __restrict__ tmp, int n) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t dst = cellStart[cellOf[i]] + slotOf[i];
+    tmp[dst] = make_uint2(fbits(vel[i].w), (uint32_t)i);
+}
+
+// ---- canonical order inside each cell: rank by ascending particle id ---------------------
+// (atomic arrival order in k_bin is arbitrary, exactly like BuildGrid.comp's atomicExchange;
+// this pass removes that freedom.)  order[s] = source index of the particle in sorted slot s.
+__global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,
+                                                 const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n) {
+    int d = blockIdx.x * kBlock + threadIdx.x;
+    if (d >= n) return;
+    uint2 me = tmp[d];
+    uint32_t c = cellOf[me.y];
+    uint32_t s = cellStart[c], e = cellStart[c + 1];
+    uint32_t rank = 0;
+    for (uint32_t q = s; q < e; ++q) rank += (tmp[q].x < me.x) ? 1u : 0u;
+    order[s + rank] = me.y;
+}
+
+// ---- variant A: per-particle gather straight from global memory --------------------------
+// One thread per sorted slot.  Neighbour cells are visited in ascending cell index
+// (dz outer, dy, dx inner); the three cells of one (dz,dy) row are contiguous in the sorted
+// order, so each row is ONE contiguous candidate range.
+template <class F>
+__device__ __forceinline__ void for_each_candidate(const SimK& k, int cx, int cy, int cz,
+                                                   const uint32_t* __restrict__ cellStart, F&& f) {
+    const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int nz = cz + dz;
+        if (nz < 0 || nz >= k.gz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ny = cy + dy;
+            if (ny < 0 || ny >= k.gy) continue;
+            const int rowBase = (nz * k.gy + ny) * k.gx;
+            const uint32_t qs = cellStart[rowBase + xlo], qe = cellStart[rowBase + xhi + 1];
+            for (uint32_t q = qs; q < qe; ++q) f(q);
+        }
+    }
+}
+
+struct StateIn {
+    const float4* __restrict__ pos;
+    const float4* __restrict__ vel;
+    const float2* __restrict__ rp;
+    const float* __restrict__ foam;
+};
+struct StateOut {
+    float4* __restrict__ pos;
+    float4* __restrict__ vel;
+    float2* __restrict__ rp;
+    float* __restrict__ foam;
+    float4* __restrict__ acc;
+};
+
+// Ghost branch of SPHFluid.comp:72-83 and the common epilogue (OBB + store).
+__device__ __forceinline__ void store_particle(const SimK& k, const StateOut& out, int s, uint32_t flags, uint32_t id,
+                                               Own& o, float foamOut) {
+    if (!(flags & F_GHOSTNZ)) obb_apply(k, o.px, o.py, o.pz, o.vx, o.vy, o.vz);   // OBBConstraints.comp:46
+    out.pos[s] = make_float4(o.px, o.py, o.pz, bitsf(flags));
+    out.vel[s] = make_float4(o.vx, o.vy, o.vz, bitsf(id));
+    out.rp[s] = make_float2(o.rho, o.prs);
+    out.foam[s] = foamOut;
+    out.acc[s] = make_float4(o.ax, o.ay, o.az, 0.0f);
+}
+
+// SPHFluid.comp main() for the particle in sorted slot s, neighbours gathered from global
+// memory through order[] (variant A, and the exact fallback of the tiled kernel).
+__device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in, const StateOut& out,
+                                               const uint32_t* __restrict__ order, const uint32_t* __restrict__ cellStart, int s) {
+    const uint32_t src = order[s];
+    const float4 P = in.pos[src], V = in.vel[src];
+    const float2 RP = in.rp[src];
+    const float foamIn = in.foam[src];
+    const uint32_t flags = fbits(P.w), id = fbits(V.w);
+    Own o;
+    own_reset(o);
+    o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = RP.x; o.prs = RP.y;
+    if (flags & F_GHOST1) {                                  // SPHFluid.comp:72-83
+        if (!(flags & F_INACTIVE)) { o.vx = o.vy = o.vz = 0.0f; o.rho = k.rho0; o.prs = 0.0f; }
+        out.pos[s] = P;
+        out.vel[s] = make_float4(o.vx, o.vy, o.vz, V.w);
+        out.rp[s] = make_float2(o.rho, o.prs);
+        out.foam[s] = foamIn;
+        out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
+    const int cy = cell_axis(P.y, k.gminy, k.cellSize, k.gy);
+    const int cz = cell_axis(P.z, k.gminz, k.cellSize, k.gz);
+
+    for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
+        const float4 J = in.pos[order[q]];
+        pair_density(k, o, J.x, J.y, J.z);
+    });
+    finish_density(k, o);
+    for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
+        if ((int)q == s) return;
+        const uint32_t j = order[q];
+        const float4 J = in.pos[j], JV = in.vel[j];
+        const float2 JR = in.rp[j];
+        pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x, JR.y);
+    });
+    integrate(k, o);
+    for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
+        if ((int)q == s) return;
+        const uint32_t j = order[q];
+        const float4 J = in.pos[j], JV = in.vel[j];
+        const float2 JR = in.rp[j];
+        pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x);
+    });
+    const float foamOut = finish_particle(k, o, foamIn);
+    store_particle(k, out, s, flags, id, o, foamOut);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sph_gather(SimK k, StateIn in, StateOut out, const uint32_t* __restrict__ order,
+                                                       const uint32_t* __restrict__ cellStart, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    sph_gather_one(k, in, out, order, cellStart, s);
+}
+
+// ---- public AoS update (original order; the array is never permuted) ---------------------
+// Writes exactly the fields SPHFluid.comp/OBBConstraints.comp change: pos.xyz, vel.xyz,
+// acc.xyzw, density, pressure, padA (fluid); vel/acc = 0, density = rho0, pressure = 0
+// (active ghost, SPHFluid.comp:77-81); nothing for an inactive ghost (:73-76).
+__global__ __launch_bounds__(kBlock) void k_writeback(SphParticle* __restrict__ aos, const float4* __restrict__ pos,
+                                                      const float4* __restrict__ vel, const float2* __restrict__ rp,
+                                                      const float* __restrict__ foam, const float4* __restrict__ acc,
+                                                      uint32_t idBase, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const float4 P = pos[s], V = vel[s];
+    const uint32_t flags = fbits(P.w);
+    const uint32_t id = fbits(V.w) - idBase;
+    if ((flags & F_GHOST1) && (flags & F_INACTIVE)) return;
+    float* rec = reinterpret_cast<float*>(aos + id);
+    const float2 RP = rp[s];
+    if (flags & F_GHOST1) {
+        rec[4] = 0.0f; rec[5] = 0.0f; rec[6] = 0.0f; rec[7] = 0.0f;
+        rec[8] = 0.0f; rec[9] = 0.0f; rec[10] = 0.0f; rec[11] = 0.0f;
+        rec[12] = RP.x; rec[13] = RP.y;
+        return;
+    }
+    const float4 A = acc[s];
+    rec[0] = P.x; rec[1] = P.y; rec[2] = P.z;
+    rec[4] = V.x; rec[5] = V.y; rec[6] = V.z;
+    *reinterpret_cast<float4*>(rec + 8) = A;
+    rec[12] = RP.x; rec[13] = RP.y; rec[14] = foam[s];
+}
+
+// ---- WaveImpulse.comp:30-46 on the internal state (and on the AoS when it is current) -----
+struct WaveK {
+    float amplitude, kk, phase, ndx, ndy, ndz, yMin, yMax;
+};
+__global__ __launch_bounds__(kBlock) void k_wave_impulse(WaveK w, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                         SphParticle* __restrict__ aosOrNull, uint32_t idBase, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const float4 P = pos[s];
+    if (fbits(P.w) & F_GHOSTNZ) return;
+    if (P.y < w.yMin || P.y > w.yMax) return;
+    float4 V = vel[s];
+    const float theta = fmaf(w.kk, dot3(P.x, P.y, P.z, w.ndx, w.ndy, w.ndz), w.phase);
+    const float kick = w.amplitude * sph_sinf(theta);
+    V.x = fmaf(w.ndx, kick, V.x); V.y = fmaf(w.ndy, kick, V.y); V.z = fmaf(w.ndz, kick, V.z);
+    vel[s] = V;
+    if (aosOrNull) {
+        float* rec = reinterpret_cast<float*>(aosOrNull + (fbits(V.w) - idBase));
+        rec[4] = V.x; rec[5] = V.y; rec[6] = V.z;
+    }
+}
+
+// ---- test support: per-cell counts in the reference's cell indexing -------------------------
+__global__ __launch_bounds__(kBlock) void k_debug_cells(const uint32_t* __restrict__ cellStart, int32_t* __restrict__ cellCount, int numCells) {
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c < numCells) cellCount[c] = (int32_t)(cellStart[c + 1] - cellStart[c]);
+}
+__global__ __launch_bounds__(kBlock) void k_debug_particle_cell(SimK k, const float4* __restrict__ pos, const float4* __restrict__ vel,
+                                                                int32_t* __restrict__ particleCell, uint32_t idBase, int n) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    float4 p = pos[s];
+    int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
+    int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
+    int cz = cell_axis(p.z, k.gminz, k.cellSize, k.gz);
+    particleCell[fbits(vel[s].w) - idBase] = (cz * k.gy + cy) * k.gx + cx;
+}
+
+}  // namespace sph

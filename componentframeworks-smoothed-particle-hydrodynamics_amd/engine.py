@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's `SPHFluidGPU` class over the C-ABI (include/sph_abi.h).
+
+The reference boundary is the C++ class SPHFluidGPU
+(/root/reference/ComponentFramework/SPHFluid3D.h:26-210): public methods plus public
+`param_*` data members that the caller pokes directly (Scene0p.cpp:936-1056) and that are
+re-read at every DispatchCompute (SPHFluid3D.cpp:458-506).  This module keeps those names:
+`DispatchCompute`, `ResetSimulation`, `ApplyWaveImpulse`, `EffectiveHalf`, `GetNumFluids`,
+`ComputeGridExtents`, `param_h` ... `param_wallFriction`, `numParticles`, `particles`,
+`gridSizeX/Y/Z`, `numCells`, `gridMinV`, `cellSize`.  The C++ twin of this file is
+include/SPHFluidGPU_hip.hpp.
+
+There is no CPU fallback: if libsph_hip.so is missing or HIP has no device, construction
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+FLT_MAX = 3.4028234663852886e38
+
+# 80-byte record, SPHFluid3D.h:12-24
+PARTICLE_DTYPE = np.dtype(
+    [
+        ("pos", "<f4", (4,)), ("vel", "<f4", (4,)), ("acc", "<f4", (4,)),
+        ("density", "<f4"), ("pressure", "<f4"), ("padA", "<f4"), ("padB", "<f4"),
+        ("isGhost", "<i4"), ("isActive", "<i4"), ("padC", "<i4"), ("pad0", "<i4"),
+    ]
+)
+assert PARTICLE_DTYPE.itemsize == 80
+
+
+class SphParams(C.Structure):
+    """struct SphParams of include/sph_abi.h (param_* members, SPHFluid3D.h:94-124)."""
+
+    _fields_ = [
+        ("param_h", C.c_float), ("param_mass", C.c_float), ("param_restDensity", C.c_float),
+        ("param_gasConstant", C.c_float), ("param_viscosity", C.c_float),
+        ("param_gravityY", C.c_float), ("param_gravityX", C.c_float), ("param_gravityZ", C.c_float),
+        ("param_surfaceTension", C.c_float), ("param_timeStep", C.c_float),
+        ("param_pause", C.c_int32),
+        ("param_useJitter", C.c_int32), ("param_jitterAmp", C.c_float),
+        ("param_foamGen", C.c_float), ("param_foamVelRef", C.c_float),
+        ("param_boxCenter", C.c_float * 3), ("param_boxHalf", C.c_float * 3), ("param_boxEulerDeg", C.c_float * 3),
+        ("param_shapeType", C.c_int32), ("param_shapeAux", C.c_float * 3),
+        ("param_mixPattern", C.c_int32), ("param_dyePattern", C.c_int32),
+        ("param_wallRestitution", C.c_float), ("param_wallFriction", C.c_float),
+        ("grid_cap", C.c_int32),
+    ]
+
+
+class SphGridInfo(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 3), ("numCells", C.c_int32), ("gridMin", C.c_float * 3), ("cellSize", C.c_float)]
+
+
+# option / kernel-class constants of sph_abi.h
+SPH_OPT_NEIGHBOR_KERNEL, SPH_OPT_GRID_BUILD, SPH_OPT_AOS_MODE, SPH_OPT_TIMING, SPH_OPT_DEBUG = 1, 2, 3, 4, 100
+KERNEL_CLASSES = ("bin", "scan", "scatter", "sph", "writeback", "impulse", "other")
+
+# every symbol include/sph_abi.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "sph_abi_version", "sph_params_default", "sph_rotation_mat3", "sph_effective_half",
+    "sph_compute_grid_extents", "sph_spawn_particles", "sph_last_error", "sph_create",
+    "sph_create_from_particles", "sph_destroy", "sph_reset", "sph_set_params", "sph_get_params",
+    "sph_set_option", "sph_get_option", "sph_dispatch", "sph_dispatch_n", "sph_apply_wave_impulse",
+    "sph_num_particles", "sph_grid_info", "sph_upload_particles", "sph_download_particles",
+    "sph_device_particles", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
+)
+
+
+class SphError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library(build_if_missing: bool = True) -> C.CDLL:
+    """Load libsph_hip.so (building it in-tree first if asked and needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        _build.build()
+    if not os.path.exists(_build.LIB_PATH):
+        raise SphError(f"{_build.LIB_PATH} is missing: run __graft_entry__.build(); there is no CPU fallback")
+    L = C.CDLL(_build.LIB_PATH)
+    vp, pp, gp = C.c_void_p, C.POINTER(SphParams), C.POINTER(SphGridInfo)
+    f3 = C.POINTER(C.c_float)
+    L.sph_abi_version.restype = C.c_int
+    L.sph_last_error.restype = C.c_char_p
+    L.sph_params_default.argtypes = [pp]
+    L.sph_rotation_mat3.argtypes = [f3, f3]
+    L.sph_effective_half.argtypes = [pp, f3]
+    L.sph_compute_grid_extents.argtypes = [pp, gp]
+    L.sph_spawn_particles.argtypes = [pp, C.c_size_t, C.c_uint32, vp, C.POINTER(C.c_size_t), f3]
+    L.sph_create.argtypes = [C.POINTER(vp), C.c_size_t, pp, C.c_uint32, vp]
+    L.sph_create_from_particles.argtypes = [C.POINTER(vp), vp, C.c_size_t, pp, vp]
+    L.sph_destroy.argtypes = [vp]
+    L.sph_reset.argtypes = [vp, C.c_size_t, C.c_uint32]
+    L.sph_set_params.argtypes = [vp, pp]
+    L.sph_get_params.argtypes = [vp, pp]
+    L.sph_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.sph_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.sph_dispatch.argtypes = [vp, C.c_float]
+    L.sph_dispatch_n.argtypes = [vp, C.c_float, C.c_int]
+    L.sph_apply_wave_impulse.argtypes = [vp, C.c_float, C.c_float, C.c_float, f3, C.c_float, C.c_float]
+    L.sph_num_particles.argtypes = [vp]
+    L.sph_num_particles.restype = C.c_size_t
+    L.sph_grid_info.argtypes = [vp, gp]
+    L.sph_upload_particles.argtypes = [vp, vp, C.c_size_t]
+    L.sph_download_particles.argtypes = [vp, vp, C.c_size_t]
+    L.sph_device_particles.argtypes = [vp, C.POINTER(vp)]
+    L.sph_initial_particles.argtypes = [vp, vp, C.c_size_t]
+    L.sph_download_grid.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+    L.sph_sync.argtypes = [vp]
+    L.sph_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        msg = load_library().sph_last_error()
+        raise SphError(f"sph C-ABI error {rc}: {msg.decode() if msg else '?'}")
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def default_params(**overrides) -> SphParams:
+    p = SphParams()
+    _check(load_library().sph_params_default(C.byref(p)))
+    for k, v in overrides.items():
+        cur = getattr(p, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def compute_grid_extents(p: SphParams) -> SphGridInfo:
+    g = SphGridInfo()
+    _check(load_library().sph_compute_grid_extents(C.byref(p), C.byref(g)))
+    return g
+
+
+def rotation_mat3(euler_deg) -> np.ndarray:
+    out = (C.c_float * 9)()
+    _check(load_library().sph_rotation_mat3(_f3(euler_deg), out))
+    return np.array(out, np.float32)
+
+
+def effective_half(p: SphParams) -> np.ndarray:
+    out = (C.c_float * 3)()
+    _check(load_library().sph_effective_half(C.byref(p), out))
+    return np.array(out, np.float32)
+
+
+def spawn_particles(p: SphParams, n_requested: int, seed: int):
+    buf = np.zeros(max(n_requested, 1), PARTICLE_DTYPE)
+    n = C.c_size_t()
+    mass = C.c_float()
+    _check(load_library().sph_spawn_particles(C.byref(p), n_requested, seed, buf.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(mass)))
+    return buf[: n.value].copy(), float(mass.value)
+
+
+_PARAM_NAMES = {f[0] for f in SphParams._fields_}
+
+
+class SPHFluidGPU:
+    """Drop-in for the reference class of the same name (SPHFluid3D.h:26).
+
+    SPHFluidGPU(numParticles)                    -> spawn as InitializeParticles does (seeded)
+    SPHFluidGPU.from_particles(records, params)  -> caller-provided 80-byte records
+    """
+
+    def __init__(self, numParticles_: int = 50000, params: SphParams | None = None, seed: int = 1, stream: int | None = None,
+                 _particles: np.ndarray | None = None):
+        L = load_library()
+        object.__setattr__(self, "_L", L)
+        object.__setattr__(self, "_p", params if params is not None else default_params())
+        object.__setattr__(self, "_h", C.c_void_p())
+        object.__setattr__(self, "numParticles", int(numParticles_))
+        object.__setattr__(self, "seed", int(seed))
+        if _particles is not None:
+            arr = np.ascontiguousarray(_particles, dtype=PARTICLE_DTYPE)
+            _check(L.sph_create_from_particles(C.byref(self._h), arr.ctypes.data_as(C.c_void_p), len(arr), C.byref(self._p), stream))
+        else:
+            _check(L.sph_create(C.byref(self._h), self.numParticles, C.byref(self._p), self.seed, stream))
+        _check(L.sph_get_params(self._h, C.byref(self._p)))   # spawn overwrote param_mass (SPHFluid3D.cpp:92)
+
+    @classmethod
+    def from_particles(cls, particles: np.ndarray, params: SphParams, stream: int | None = None) -> "SPHFluidGPU":
+        return cls(len(particles), params=params, stream=stream, _particles=particles)
+
+    # -- public param_* members ----------------------------------------------------------
+    def __getattr__(self, name):
+        if name in _PARAM_NAMES:
+            v = getattr(object.__getattribute__(self, "_p"), name)
+            return list(v) if hasattr(v, "__len__") else v
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in _PARAM_NAMES:
+            cur = getattr(self._p, name)
+            if hasattr(cur, "__len__"):
+                for i, x in enumerate(value):
+                    cur[i] = x
+            else:
+                setattr(self._p, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    @property
+    def params(self) -> SphParams:
+        return self._p
+
+    # -- reference methods ---------------------------------------------------------------
+    def DispatchCompute(self, overrideDt: float = -1.0):            # SPHFluid3D.cpp:431
+        _check(self._L.sph_set_params(self._h, C.byref(self._p)))  # members are re-read every dispatch (:458-506)
+        _check(self._L.sph_dispatch(self._h, overrideDt))
+
+    SimulateSubstep = DispatchCompute   # BASELINE.json's name for the same entry point
+
+    def DispatchN(self, n: int, overrideDt: float = -1.0):           # Scene0p.cpp:3720-3739 loop
+        _check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        _check(self._L.sph_dispatch_n(self._h, overrideDt, int(n)))
+
+    def ResetSimulation(self, seed: int | None = None):             # SPHFluid3D.cpp:713
+        if seed is not None:
+            self.seed = int(seed)
+        _check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        _check(self._L.sph_reset(self._h, self.numParticles, self.seed))
+        _check(self._L.sph_get_params(self._h, C.byref(self._p)))
+
+    def ApplyWaveImpulse(self, amplitude, wavelength, phase, dir, yMin=-FLT_MAX, yMax=FLT_MAX):   # SPHFluid3D.cpp:604
+        _check(self._L.sph_apply_wave_impulse(self._h, amplitude, wavelength, phase, _f3(dir), yMin, yMax))
+
+    def EffectiveHalf(self):                                         # SPHFluid3D.h:127
+        return effective_half(self._p)
+
+    def ComputeGridExtents(self):                                    # SPHFluid3D.cpp:354
+        return compute_grid_extents(self._p)
+
+    def GetNumFluids(self) -> int:                                   # SPHFluid3D.cpp:601
+        return int(self._L.sph_num_particles(self._h))
+
+    # -- reference data members ----------------------------------------------------------
+    @property
+    def particles(self) -> np.ndarray:
+        """Host copy of the INITIAL records (never refreshed, as in the reference)."""
+        n = self.GetNumFluids()
+        out = np.zeros(n, PARTICLE_DTYPE)
+        _check(self._L.sph_initial_particles(self._h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def _grid(self) -> SphGridInfo:
+        g = SphGridInfo()
+        _check(self._L.sph_grid_info(self._h, C.byref(g)))
+        return g
+
+    gridSizeX = property(lambda self: self._grid().dims[0])
+    gridSizeY = property(lambda self: self._grid().dims[1])
+    gridSizeZ = property(lambda self: self._grid().dims[2])
+    numCells = property(lambda self: self._grid().numCells)
+    gridMinV = property(lambda self: list(self._grid().gridMin))
+    cellSize = property(lambda self: self._grid().cellSize)
+
+    # -- engine extras -------------------------------------------------------------------
+    def set_option(self, option: int, value: int):
+        _check(self._L.sph_set_option(self._h, option, value))
+
+    def upload(self, particles: np.ndarray):
+        arr = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+        _check(self._L.sph_upload_particles(self._h, arr.ctypes.data_as(C.c_void_p), len(arr)))
+
+    def download(self) -> np.ndarray:
+        n = self.GetNumFluids()
+        out = np.zeros(n, PARTICLE_DTYPE)
+        _check(self._L.sph_download_particles(self._h, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def device_particles(self) -> int:
+        """Device address of the 80-byte AoS (the `ssbo` renderers bind, Scene0p.cpp:1625)."""
+        p = C.c_void_p()
+        _check(self._L.sph_device_particles(self._h, C.byref(p)))
+        return int(p.value)
+
+    def download_grid(self):
+        g = compute_grid_extents(self._p)
+        n = self.GetNumFluids()
+        cnt = np.zeros(g.numCells, np.int32)
+        pc = np.zeros(max(n, 1), np.int32)
+        _check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        _check(self._L.sph_download_grid(self._h, cnt.ctypes.data_as(C.c_void_p), g.numCells, pc.ctypes.data_as(C.c_void_p), n))
+        return cnt, pc[:n]
+
+    def sync(self):
+        _check(self._L.sph_sync(self._h))
+
+    def kernel_times(self, reset: bool = False):
+        ms = (C.c_double * len(KERNEL_CLASSES))()
+        cnt = (C.c_int64 * len(KERNEL_CLASSES))()
+        _check(self._L.sph_kernel_times(self._h, ms, cnt, 1 if reset else 0))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.sph_destroy(self._h)
+            object.__setattr__(self, "_h", C.c_void_p())
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

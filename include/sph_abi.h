@@ -1,0 +1,197 @@
+/*
+ * sph_abi.h -- C-ABI of the MI355X-native SPH substep engine (libsph_hip.so).
+ *
+ * The reference has no plugin/FFI layer: its boundary is the concrete C++ class
+ * SPHFluidGPU (ComponentFramework/SPHFluid3D.h:26-210) that Scene0p holds by raw
+ * pointer (Scene0p.h:396).  Each entry point below names the reference member it
+ * replaces.  Plain pointers and sizes only; no torch / STL types cross this line.
+ * The header-only C++ shim include/SPHFluidGPU_hip.hpp re-creates the class surface
+ * (same member names) on top of these calls; INTEGRATION.md shows the swap.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative SPH_ERR_* otherwise, and
+ *    leaves a message for sph_last_error() (thread-local);
+ *  - calls enqueue work on the engine's HIP stream and return without waiting;
+ *    sph_download_particles() and sph_sync() synchronise;
+ *  - one host thread per engine (as the reference: everything runs on the GL thread,
+ *    SceneManager.cpp:69-93);
+ *  - there is NO CPU fallback: without a HIP device every compute call fails with
+ *    SPH_ERR_HIP.
+ */
+#ifndef SPH_ABI_H
+#define SPH_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_ABI_VERSION 1
+
+enum {
+    SPH_OK = 0,
+    SPH_ERR_ARG = -1,      /* bad argument / null handle                    */
+    SPH_ERR_HIP = -2,      /* HIP runtime error (message has hipGetErrorString) */
+    SPH_ERR_STATE = -3,    /* call not valid in the engine's current state   */
+    SPH_ERR_CAPACITY = -4  /* a fixed-capacity buffer (ghosts, migrants) overflowed */
+};
+
+/* 80-byte particle record: struct SPHParticle, SPHFluid3D.h:12-24 (std430 twin:
+ * shaders/SPHFluid.comp:5-17).  Index i is the same particle forever (renderers
+ * index by gl_InstanceID, Scene0p.cpp:1625-1637): the engine never permutes this
+ * array, whatever it sorts internally. */
+typedef struct SphParticle {
+    float pos[4];
+    float vel[4];
+    float acc[4];
+    float density;
+    float pressure;
+    float padA;      /* foam factor, SPHFluid.comp:209-217          */
+    float padB;      /* dye, SPHFluid3D.cpp:316-329                 */
+    int32_t isGhost;
+    int32_t isActive;
+    int32_t padC;    /* colour group, SPHFluid3D.cpp:307-311        */
+    int32_t pad0;
+} SphParticle;
+
+/* The public param_* members of SPHFluidGPU, SPHFluid3D.h:94-124, field for field.
+ * Sampled at every sph_dispatch(), like the per-dispatch uniform uploads at
+ * SPHFluid3D.cpp:458-506, so edits take effect on the next substep. */
+typedef struct SphParams {
+    float param_h;                 /* :94  */
+    float param_mass;              /* :95  (overwritten by spawn: rho0*(0.85h)^3, SPHFluid3D.cpp:92) */
+    float param_restDensity;       /* :96  */
+    float param_gasConstant;       /* :97  */
+    float param_viscosity;         /* :98  */
+    float param_gravityY;          /* :99  */
+    float param_gravityX;          /* :100 */
+    float param_gravityZ;          /* :101 */
+    float param_surfaceTension;    /* :102 */
+    float param_timeStep;          /* :103 */
+    int32_t param_pause;           /* :104 (bool) */
+    int32_t param_useJitter;       /* :106 (bool) */
+    float param_jitterAmp;         /* :107 */
+    float param_foamGen;           /* :109 */
+    float param_foamVelRef;        /* :110 */
+    float param_boxCenter[3];      /* :112 */
+    float param_boxHalf[3];        /* :113 */
+    float param_boxEulerDeg[3];    /* :116 */
+    int32_t param_shapeType;       /* :117 */
+    float param_shapeAux[3];       /* :119 */
+    int32_t param_mixPattern;      /* :121 */
+    int32_t param_dyePattern;      /* :122 */
+    float param_wallRestitution;   /* :123 */
+    float param_wallFriction;      /* :124 */
+    /* engine extension, no reference member: per-axis cell-count cap of
+     * ComputeGridExtents (hard-coded 160 at SPHFluid3D.cpp:370). */
+    int32_t grid_cap;
+} SphParams;
+
+typedef struct SphGridInfo {       /* gridSizeX/Y/Z, numCells, gridMinV, cellSize: SPHFluid3D.h:63-66 */
+    int32_t dims[3];
+    int32_t numCells;
+    float gridMin[3];
+    float cellSize;
+} SphGridInfo;
+
+typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHFluidGPU owns its GL buffers, SPHFluid3D.cpp:61-83) */
+
+/* ---- engine options (sph_set_option) ------------------------------------------- */
+enum {
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* 0 = LDS-tiled 27-cell pass (default), 1 = per-particle global gather */
+    SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
+    SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
+    SPH_OPT_TIMING = 4,          /* hipEvents around kernels for sph_kernel_times(): 1 = every kernel, 2 = only the SPH pass */
+    /* test / tuning hooks */
+    SPH_OPT_DEBUG = 100,         /* bit 0: force neighbour-list overflow, bit 1: force the sweep-3 re-scan, bit 2: force tile overflow */
+    SPH_OPT_TILE_X = 101,        /* tile size in cells of the LDS-tiled pass (defaults 8 x 4 x 4) */
+    SPH_OPT_TILE_Y = 102,
+    SPH_OPT_TILE_Z = 103
+};
+
+/* ---- host-only helpers (no device needed) --------------------------------------- */
+int sph_abi_version(void);
+/* Defaults of SPHFluid3D.h:94-124 (+ grid_cap = 160). */
+int sph_params_default(SphParams* out);
+/* MakeRotationMat3XYZ, SPHFluid3D.cpp:13-30: column-major world_from_box. */
+int sph_rotation_mat3(const float eulerDeg[3], float outM[9]);
+/* SPHFluidGPU::EffectiveHalf(), SPHFluid3D.h:127-158. */
+int sph_effective_half(const SphParams* params, float outHalf[3]);
+/* SPHFluidGPU::ComputeGridExtents(), SPHFluid3D.cpp:354-376. */
+int sph_compute_grid_extents(const SphParams* params, SphGridInfo* out);
+/* SPHFluidGPU::InitializeParticles() standard-fill branch, SPHFluid3D.cpp:85-102,159-332,
+ * with an explicit seed (the reference seeds from time(nullptr), :99).  Writes at most
+ * nRequested records, returns the count produced through *nOut and param_mass (:92)
+ * through *massOut. */
+int sph_spawn_particles(const SphParams* params, size_t nRequested, uint32_t seed,
+                        SphParticle* out, size_t* nOut, float* massOut);
+const char* sph_last_error(void);
+
+/* ---- lifetime ------------------------------------------------------------------- */
+/* SPHFluidGPU::SPHFluidGPU(size_t), SPHFluid3D.cpp:32-59: spawn + allocate + upload.
+ * `stream` is a hipStream_t (or NULL for an engine-owned stream). */
+int sph_create(SphEngine** out, size_t nRequested, const SphParams* params, uint32_t seed, void* stream);
+/* Same, but with caller-provided initial records instead of the spawn (bench / tests). */
+int sph_create_from_particles(SphEngine** out, const SphParticle* particles, size_t n,
+                              const SphParams* params, void* stream);
+/* SPHFluidGPU::~SPHFluidGPU(), SPHFluid3D.cpp:61-83. */
+int sph_destroy(SphEngine* e);
+/* SPHFluidGPU::ResetSimulation(), SPHFluid3D.cpp:713-731: respawn with numParticles
+ * requested (Scene0p.cpp:1403-1408 writes numParticles before the reset). Invalidates
+ * the pointer returned by sph_device_particles(). */
+int sph_reset(SphEngine* e, size_t nRequested, uint32_t seed);
+
+/* ---- parameters ----------------------------------------------------------------- */
+int sph_set_params(SphEngine* e, const SphParams* params);
+int sph_get_params(const SphEngine* e, SphParams* out);
+int sph_set_option(SphEngine* e, int option, int value);
+int sph_get_option(const SphEngine* e, int option, int* value);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+/* SPHFluidGPU::DispatchCompute(float overrideDt = -1), SPHFluid3D.cpp:431-522:
+ * ClearGrid -> BuildGrid -> SPHFluid -> OBBConstraints. No-op when param_pause. */
+int sph_dispatch(SphEngine* e, float overrideDt);
+/* n back-to-back substeps (the reel-export loop, Scene0p.cpp:3720-3739). */
+int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps);
+/* SPHFluidGPU::ApplyWaveImpulse, SPHFluid3D.cpp:604-623 + shaders/WaveImpulse.comp. */
+int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, float phase,
+                           const float dir[3], float yMin, float yMax);
+
+/* ---- data ------------------------------------------------------------------------ */
+size_t sph_num_particles(const SphEngine* e);            /* particles.size() / GetNumFluids() */
+int sph_grid_info(const SphEngine* e, SphGridInfo* out); /* gridSize*, numCells, gridMinV, cellSize */
+/* glBufferData of the particle SSBO, SPHFluid3D.cpp:417-429 (n must equal sph_num_particles). */
+int sph_upload_particles(SphEngine* e, const SphParticle* host, size_t n);
+/* Read-back of the SSBO (the reference never reads back; needed for parity tests). Synchronises. */
+int sph_download_particles(SphEngine* e, SphParticle* host, size_t n);
+/* Device pointer of the 80-byte AoS in original order: the `ssbo` renderers bind
+ * (Scene0p.cpp:1625,2627,3065,3142). Borrowed, read-only, invalidated by reset/destroy. */
+int sph_device_particles(SphEngine* e, const SphParticle** devPtr);
+/* Initial host-side records (SPHFluidGPU::particles: initial state only, never refreshed). */
+int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n);
+/* Grid as BuildGrid.comp defines it, for tests: cellCount[numCells] and
+ * particleCell[n] (binding 3) in the reference's cell indexing. Synchronises. */
+int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* particleCell, size_t n);
+int sph_sync(SphEngine* e);
+
+/* ---- measurement ----------------------------------------------------------------- */
+enum {
+    SPH_K_BIN = 0,      /* cell index + histogram   (BuildGrid.comp)            */
+    SPH_K_SCAN = 1,     /* exclusive scan + clear   (ClearGrid.comp)            */
+    SPH_K_SCATTER = 2,  /* counting-sort scatter + canonical rank               */
+    SPH_K_SPH = 3,      /* 27-cell density+force+integrate+XSPH (+fused OBB)    */
+    SPH_K_WRITEBACK = 4,/* 80-byte AoS update                                   */
+    SPH_K_IMPULSE = 5,  /* WaveImpulse                                          */
+    SPH_K_OTHER = 6,
+    SPH_K_COUNT = 7
+};
+/* Accumulated hipEvent milliseconds and launch counts per kernel class since the
+ * last reset (SPH_OPT_TIMING must be 1). Synchronises. */
+int sph_kernel_times(SphEngine* e, double msOut[SPH_K_COUNT], int64_t launchesOut[SPH_K_COUNT], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_ABI_H */

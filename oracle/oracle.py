@@ -1,0 +1,420 @@
+"""ctypes front end for the CPU oracle (oracle/sph_oracle.c) plus an independent
+brute-force numpy restatement of the same shader math.
+
+TEST INFRASTRUCTURE ONLY (see the header of sph_oracle.c): imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product package.
+PARITY UNPINNED: the reference has no tests or fixtures for this path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+# 80-byte record, /root/reference/ComponentFramework/SPHFluid3D.h:12-24
+PARTICLE_DTYPE = np.dtype(
+    [
+        ("pos", "<f4", (4,)),
+        ("vel", "<f4", (4,)),
+        ("acc", "<f4", (4,)),
+        ("density", "<f4"),
+        ("pressure", "<f4"),
+        ("padA", "<f4"),
+        ("padB", "<f4"),
+        ("isGhost", "<i4"),
+        ("isActive", "<i4"),
+        ("padC", "<i4"),
+        ("pad0", "<i4"),
+    ]
+)
+assert PARTICLE_DTYPE.itemsize == 80
+
+
+class OParams(C.Structure):
+    """Mirror of OParams in sph_oracle.c (param_* members, SPHFluid3D.h:94-124)."""
+
+    _fields_ = [
+        ("h", C.c_float), ("mass", C.c_float), ("restDensity", C.c_float),
+        ("gasConstant", C.c_float), ("viscosity", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("surfaceTension", C.c_float), ("timeStep", C.c_float),
+        ("pause", C.c_int32),
+        ("useJitter", C.c_int32), ("jitterAmp", C.c_float),
+        ("foamGen", C.c_float), ("foamVelRef", C.c_float),
+        ("boxCenter", C.c_float * 3), ("boxHalf", C.c_float * 3), ("boxEulerDeg", C.c_float * 3),
+        ("shapeType", C.c_int32), ("shapeAux", C.c_float * 3),
+        ("mixPattern", C.c_int32), ("dyePattern", C.c_int32),
+        ("wallRestitution", C.c_float), ("wallFriction", C.c_float),
+        ("gridCap", C.c_int32),
+    ]
+
+
+class OGrid(C.Structure):
+    _fields_ = [
+        ("dims", C.c_int32 * 3),
+        ("numCells", C.c_int32),
+        ("gridMin", C.c_float * 3),
+        ("cellSize", C.c_float),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with the committed Makefile (gcc only, no reference sources)."""
+    src = os.path.join(_HERE, "sph_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        pp = C.POINTER(OParams)
+        vp = C.c_void_p
+        L.sph_oracle_sizeof_particle.restype = C.c_int
+        L.sph_oracle_sizeof_params.restype = C.c_int
+        L.sph_oracle_default_params.argtypes = [pp]
+        L.sph_oracle_sinf.argtypes = [C.c_float]
+        L.sph_oracle_sinf.restype = C.c_float
+        L.sph_oracle_rotation.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.sph_oracle_effective_half.argtypes = [pp, C.POINTER(C.c_float)]
+        L.sph_oracle_grid_extents.argtypes = [pp, C.POINTER(OGrid)]
+        L.sph_oracle_build_grid.argtypes = [vp, C.c_int, C.POINTER(OGrid), vp, vp, vp, vp, vp]
+        L.sph_oracle_obb.argtypes = [vp, C.c_int, pp]
+        L.sph_oracle_sph_pass.argtypes = [vp, vp, C.c_int, pp, C.c_float]
+        L.sph_oracle_substep.argtypes = [vp, vp, C.c_int, pp, C.c_float]
+        L.sph_oracle_wave_impulse.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float,
+                                              C.POINTER(C.c_float), C.c_float, C.c_float]
+        L.sph_oracle_spawn.argtypes = [pp, C.c_int, C.c_uint32, vp, C.POINTER(C.c_float)]
+        L.sph_oracle_spawn.restype = C.c_int
+        L.sph_oracle_shape_supported.argtypes = [C.c_int]
+        L.sph_oracle_shape_supported.restype = C.c_int
+        L.sph_oracle_max_threads.restype = C.c_int
+        L.sph_oracle_set_threads.argtypes = [C.c_int]
+        assert L.sph_oracle_sizeof_particle() == 80
+        assert L.sph_oracle_sizeof_params() == C.sizeof(OParams)
+        _lib = L
+    return _lib
+
+
+def default_params(**overrides) -> OParams:
+    p = OParams()
+    lib().sph_oracle_default_params(C.byref(p))
+    set_params(p, **overrides)
+    return p
+
+
+def set_params(p, **kw):
+    for k, v in kw.items():
+        cur = getattr(p, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f3(x):
+    return (C.c_float * 3)(*[float(v) for v in x])
+
+
+def grid_extents(p: OParams) -> OGrid:
+    g = OGrid()
+    lib().sph_oracle_grid_extents(C.byref(p), C.byref(g))
+    return g
+
+
+def rotation(euler_deg) -> np.ndarray:
+    out = (C.c_float * 9)()
+    lib().sph_oracle_rotation(f3(euler_deg), out)
+    return np.array(out, dtype=np.float32)
+
+
+def effective_half(p: OParams) -> np.ndarray:
+    out = (C.c_float * 3)()
+    lib().sph_oracle_effective_half(C.byref(p), out)
+    return np.array(out, dtype=np.float32)
+
+
+def build_grid(P: np.ndarray, p: OParams, linked_list: bool = False):
+    g = grid_extents(p)
+    n = len(P)
+    cell_start = np.zeros(g.numCells + 1, np.int32)
+    order = np.zeros(max(n, 1), np.int32)
+    pcell = np.zeros(max(n, 1), np.int32)
+    head = np.zeros(g.numCells, np.int32) if linked_list else None
+    nxt = np.zeros(max(n, 1), np.int32) if linked_list else None
+    lib().sph_oracle_build_grid(_ptr(P), n, C.byref(g), _ptr(cell_start), _ptr(order), _ptr(pcell),
+                                _ptr(head) if linked_list else None, _ptr(nxt) if linked_list else None)
+    out = dict(grid=g, cell_start=cell_start, order=order[:n], particle_cell=pcell[:n])
+    if linked_list:
+        out.update(cell_head=head, particle_next=nxt[:n])
+    return out
+
+
+def sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndarray:
+    out = np.zeros_like(P)
+    lib().sph_oracle_sph_pass(_ptr(P), _ptr(out), len(P), C.byref(p), dt)
+    return out
+
+
+def obb(P: np.ndarray, p: OParams) -> np.ndarray:
+    out = P.copy()
+    lib().sph_oracle_obb(_ptr(out), len(out), C.byref(p))
+    return out
+
+
+def substep(P: np.ndarray, p: OParams, dt: float = -1.0, steps: int = 1) -> np.ndarray:
+    """DispatchCompute x steps; returns a new array."""
+    cur = P.copy()
+    scratch = np.zeros_like(cur)
+    for _ in range(steps):
+        lib().sph_oracle_substep(_ptr(cur), _ptr(scratch), len(cur), C.byref(p), dt)
+    return cur
+
+
+def wave_impulse(P, amplitude, wavelength, phase, direction, y_min=-3.4028235e38, y_max=3.4028235e38):
+    out = P.copy()
+    lib().sph_oracle_wave_impulse(_ptr(out), len(out), amplitude, wavelength, phase, f3(direction), y_min, y_max)
+    return out
+
+
+def spawn(p: OParams, n_requested: int, seed: int):
+    """InitializeParticles standard fill; returns (particles, mass)."""
+    buf = np.zeros(n_requested, PARTICLE_DTYPE)
+    mass = C.c_float()
+    n = lib().sph_oracle_spawn(C.byref(p), n_requested, seed, _ptr(buf), C.byref(mass))
+    return buf[:n].copy(), float(mass.value)
+
+
+def sinf(x: float) -> float:
+    return float(lib().sph_oracle_sinf(float(x)))
+
+
+def set_threads(n: int):
+    lib().sph_oracle_set_threads(n)
+
+
+def max_threads() -> int:
+    return lib().sph_oracle_max_threads()
+
+
+# --------------------------------------------------------------------------------------
+# Independent brute-force restatement (numpy).  No cell lists, no counting sort: every
+# pair (i, j) is considered, filtered only by "j's cell is one of the 27 cells around
+# i's ENTRY cell" (which the shader's traversal implies), and accumulated in the
+# canonical order (ascending cell index of j, then ascending j).  fp32 throughout;
+# fmaf is emulated through float64 (exact product, one extra rounding that can differ
+# from a true fma in ~2^-29 of the cases, hence the 1-ulp-scale tolerance in the tests).
+# Follows shaders/SPHFluid.comp:66-221 and OBBConstraints.comp:297-330 directly.
+# --------------------------------------------------------------------------------------
+
+_F = np.float32
+
+
+def _fma(a, b, c):
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def _dot3(ax, ay, az, bx, by, bz):
+    return _fma(az, bz, _fma(ay, by, (ax * bx).astype(np.float32)))
+
+
+def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndarray:
+    n = len(P)
+    g = grid_extents(p)
+    dims = np.array(g.dims[:], np.int64)
+    gmin = np.array(g.gridMin[:], _F)
+    cs = _F(g.cellSize)
+    dt = _F(dt if dt > 0 else p.timeStep)
+    h = _F(p.h)
+    h2 = _F(h * h)
+    h3 = _F(h2 * h)
+    h6 = _F(h3 * h3)
+    h9 = _F(h6 * h3)
+    pi_f = _F(3.141592653589)
+    poly6C = _F(_F(315.0) / _F(_F(_F(64.0) * pi_f) * h9))
+    spikyC = _F(_F(-45.0) / _F(pi_f * h6))
+    viscC = _F(_F(45.0) / _F(pi_f * h6))
+    mass = _F(p.mass)
+    rho0 = _F(p.restDensity)
+    kgas = _F(p.gasConstant)
+    visc = _F(p.viscosity)
+    sigma = _F(p.surfaceTension)
+    grav = np.array(p.gravity[:], _F)
+    max_speed = _F(_F(_F(0.4) * h) / max(dt, _F(1e-6)))
+
+    pos = P["pos"][:, :3].astype(_F)
+    vel = P["vel"][:, :3].astype(_F)
+    rho_in = P["density"].astype(_F)
+    prs_in = P["pressure"].astype(_F)
+
+    q = ((pos - gmin) / cs).astype(_F)
+    cc = np.clip(np.floor(q), 0, (dims - 1).astype(_F)).astype(np.int64)
+    cell = (cc[:, 2] * dims[1] + cc[:, 1]) * dims[0] + cc[:, 0]
+
+    # neighbour matrix in canonical order, -1 padded
+    lists = []
+    for i in range(n):
+        adj = np.all(np.abs(cc - cc[i]) <= 1, axis=1)
+        idx = np.nonzero(adj)[0]
+        idx = idx[np.lexsort((idx, cell[idx]))]
+        lists.append(idx)
+    K = max(len(x) for x in lists)
+    NB = np.full((n, K), -1, np.int64)
+    for i, x in enumerate(lists):
+        NB[i, : len(x)] = x
+    ar = np.arange(n)
+
+    out = P.copy()
+    # ---- sweep 1
+    dens = np.zeros(n, _F)
+    for k in range(K):
+        j = NB[:, k]
+        ok = j >= 0
+        jj = np.where(ok, j, 0)
+        d = (pos - pos[jj]).astype(_F)
+        r2 = _dot3(d[:, 0], d[:, 1], d[:, 2], d[:, 0], d[:, 1], d[:, 2])
+        acc = ok & (r2 < h2)
+        t = (h2 - r2).astype(_F)
+        w = (poly6C * ((t * t).astype(_F) * t).astype(_F)).astype(_F)
+        dens = np.where(acc, _fma(mass, w, dens), dens)
+    dens = np.maximum(dens, _F(rho0 * _F(0.5)))
+    prs = np.maximum((kgas * (dens - rho0).astype(_F)).astype(_F), _F(0))
+
+    # ---- sweep 2
+    fP = np.zeros((n, 3), _F)
+    fV = np.zeros((n, 3), _F)
+    gC = np.zeros((n, 3), _F)
+    lapC = np.zeros(n, _F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for k in range(K):
+            j = NB[:, k]
+            ok = (j >= 0) & (j != ar)
+            jj = np.where(j >= 0, j, 0)
+            d = (pos - pos[jj]).astype(_F)
+            r = np.sqrt(_dot3(d[:, 0], d[:, 1], d[:, 2], d[:, 0], d[:, 1], d[:, 2])).astype(_F)
+            rj = rho_in[jj]
+            acc = ok & (r < h) & (rj > 0)
+            hr = (h - r).astype(_F)
+            s = (spikyC * (hr * hr).astype(_F)).astype(_F)
+            invr = (_F(1.0) / r).astype(_F)
+            gW = np.where((r > 0)[:, None], (s[:, None] * (d * invr[:, None]).astype(_F)).astype(_F), _F(0)).astype(_F)
+            i2r = (_F(1.0) / (_F(2.0) * rj).astype(_F)).astype(_F)
+            pterm = (((-mass) * (prs + prs_in[jj]).astype(_F)).astype(_F) * i2r).astype(_F)
+            mor = (mass / rj).astype(_F)
+            lapW = (viscC * hr).astype(_F)
+            for a in range(3):
+                fP[:, a] = np.where(acc, _fma(gW[:, a], pterm, fP[:, a]), fP[:, a])
+                dv = ((vel[jj, a] - vel[:, a]).astype(_F) * mor).astype(_F)
+                fV[:, a] = np.where(acc, _fma(dv, lapW, fV[:, a]), fV[:, a])
+                gC[:, a] = np.where(acc, _fma(mor, gW[:, a], gC[:, a]), gC[:, a])
+            lapC = np.where(acc, _fma(mor, lapW, lapC), lapC)
+        gl = np.sqrt(_dot3(gC[:, 0], gC[:, 1], gC[:, 2], gC[:, 0], gC[:, 1], gC[:, 2])).astype(_F)
+        sc = ((-sigma) * lapC).astype(_F)
+        fS = np.where((gl > _F(1e-6))[:, None], (sc[:, None] * (gC / gl[:, None]).astype(_F)).astype(_F), _F(0)).astype(_F)
+    accv = np.zeros((n, 3), _F)
+    nvel = np.zeros((n, 3), _F)
+    npos = np.zeros((n, 3), _F)
+    for a in range(3):
+        fG = (grav[a] * dens).astype(_F)
+        t = _fma(visc, fV[:, a], fP[:, a])
+        t = (t + fG).astype(_F)
+        t = (t + fS[:, a]).astype(_F)
+        accv[:, a] = (t / dens).astype(_F)
+        v = _fma(accv[:, a], dt, vel[:, a])
+        v = (v * _F(0.995)).astype(_F)
+        nvel[:, a] = v
+        npos[:, a] = _fma(v, dt, pos[:, a])
+
+    # ---- sweep 3 (own state updated, neighbours at entry, entry cell)
+    xs = np.zeros((n, 3), _F)
+    norm = np.zeros(n, _F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for k in range(K):
+            j = NB[:, k]
+            ok = (j >= 0) & (j != ar)
+            jj = np.where(j >= 0, j, 0)
+            d = (npos - pos[jj]).astype(_F)
+            r2 = _dot3(d[:, 0], d[:, 1], d[:, 2], d[:, 0], d[:, 1], d[:, 2])
+            rj = rho_in[jj]
+            acc = ok & (r2 < h2) & (rj > 0)
+            t = (h2 - r2).astype(_F)
+            w = (poly6C * ((t * t).astype(_F) * t).astype(_F)).astype(_F)
+            mor = (mass / rj).astype(_F)
+            for a in range(3):
+                dv = ((vel[jj, a] - nvel[:, a]).astype(_F) * w).astype(_F)
+                xs[:, a] = np.where(acc, _fma(dv, mor, xs[:, a]), xs[:, a])
+            norm = np.where(acc, (norm + w).astype(_F), norm)
+        xs = np.where((norm > 0)[:, None], (xs / norm[:, None]).astype(_F), xs).astype(_F)
+    for a in range(3):
+        nvel[:, a] = _fma(_F(0.12), xs[:, a], nvel[:, a])
+    sp = np.sqrt(_dot3(nvel[:, 0], nvel[:, 1], nvel[:, 2], nvel[:, 0], nvel[:, 1], nvel[:, 2])).astype(_F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f = (max_speed / sp).astype(_F)
+    nvel = np.where((sp > max_speed)[:, None], (nvel * f[:, None]).astype(_F), nvel).astype(_F)
+    speed = np.sqrt(_dot3(nvel[:, 0], nvel[:, 1], nvel[:, 2], nvel[:, 0], nvel[:, 1], nvel[:, 2])).astype(_F)
+    aer = (np.clip(((rho0 - dens).astype(_F) / rho0).astype(_F), 0, 1).astype(_F)
+           * np.clip((speed / max(_F(p.foamVelRef), _F(1e-3))).astype(_F), 0, 1).astype(_F)).astype(_F)
+    foam = np.maximum((aer * _F(p.foamGen)).astype(_F), (P["padA"] * _F(0.995)).astype(_F))
+
+    fluid = P["isGhost"] != 1
+    out["pos"][fluid, :3] = npos[fluid]
+    out["vel"][fluid, :3] = nvel[fluid]
+    out["acc"][fluid, :3] = accv[fluid]
+    out["acc"][fluid, 3] = 0
+    out["density"][fluid] = dens[fluid]
+    out["pressure"][fluid] = prs[fluid]
+    out["padA"][fluid] = foam[fluid]
+    gh = (P["isGhost"] == 1) & (P["isActive"] != 0)
+    out["vel"][gh] = 0
+    out["acc"][gh] = 0
+    out["density"][gh] = rho0
+    out["pressure"][gh] = 0
+    return out
+
+
+def brute_force_obb_box(P: np.ndarray, p: OParams) -> np.ndarray:
+    """OBBConstraints.comp box branch (:297-309) + response (:311-330), float64 math
+    rounded to fp32 at the end (tolerance check only, not bit-exact)."""
+    R = rotation(p.boxEulerDeg[:]).astype(np.float64).reshape(3, 3).T  # R[i, j]: row i, column j
+    c = np.array(p.boxCenter[:], np.float64)
+    half = np.array(p.boxHalf[:], np.float64)
+    out = P.copy()
+    pos = P["pos"][:, :3].astype(np.float64)
+    vel = P["vel"][:, :3].astype(np.float64)
+    pL = (pos - c) @ R
+    qL = np.clip(pL, -half, half)
+    delta = pL - qL
+    d = np.abs(delta)
+    hit = np.any(d > 0, axis=1) & (P["isGhost"] == 0)
+    ax = np.where((d[:, 0] >= d[:, 1]) & (d[:, 0] >= d[:, 2]), 0, np.where((d[:, 1] >= d[:, 0]) & (d[:, 1] >= d[:, 2]), 1, 2))
+    nL = np.zeros_like(pL)
+    nL[np.arange(len(P)), ax] = np.sign(delta[np.arange(len(P)), ax])
+    nW = nL @ R.T
+    ln = np.linalg.norm(nW, axis=1, keepdims=True)
+    nW = np.divide(nW, ln, out=np.zeros_like(nW), where=ln > 0)
+    pW = c + qL @ R.T
+    vn = np.sum(vel * nW, axis=1, keepdims=True)
+    vN = vn * nW
+    vT = vel - vN
+    vnew = -p.wallRestitution * vN + (1.0 - p.wallFriction) * vT
+    out["pos"][hit, :3] = pW[hit].astype(np.float32)
+    out["vel"][hit, :3] = vnew[hit].astype(np.float32)
+    return out

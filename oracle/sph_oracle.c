@@ -1,0 +1,709 @@
+/*
+ * sph_oracle.c -- CPU restatement of the reference's SPH substep path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
+ * this path and its GLSL compute shaders cannot be
+ * executed in the build container, so this restatement is pinned only by the
+ * analytic known-answer tests in tests/ (derived from the shader formulas) and by
+ * an independent brute-force numpy restatement (oracle/oracle.py).
+ *
+ * What is restated (paths relative to /root/reference/ComponentFramework):
+ *   shaders/ClearGrid.comp:7-10, shaders/BuildGrid.comp:21-37   -> o_build_grid
+ *   shaders/SPHFluid.comp:42-64 (kernels), :66-221 (main)       -> o_sph_one
+ *   shaders/OBBConstraints.comp:31-39, :297-309, :311-330       -> o_obb_one (box)
+ *   shaders/WaveImpulse.comp:30-46, SPHFluid3D.cpp:604-623      -> sph_oracle_wave_impulse
+ *   SPHFluid3D.cpp:13-30 (MakeRotationMat3XYZ)                  -> o_rotation
+ *   SPHFluid3D.cpp:354-376 (ComputeGridExtents), .h:127-158     -> sph_oracle_grid_extents
+ *   SPHFluid3D.cpp:431-509 (DispatchCompute)                    -> sph_oracle_substep
+ *   SPHFluid3D.cpp:85-102,159-332 (InitializeParticles std fill)-> sph_oracle_spawn
+ *
+ * Semantics this oracle FIXES because the reference leaves them open
+ * (SURVEY.md section 8a "Semantics the oracle must fix"):
+ *  1. Snapshot reads.  SPHFluid.comp reads neighbour records from the buffer every
+ *     invocation overwrites (:99,:131,:190 vs :220).  Here every neighbour read
+ *     sees the state at dispatch entry; a particle's own state evolves through the
+ *     three sweeps exactly as the shader writes it.
+ *  2. Neighbour order.  atomicExchange arrival order (BuildGrid.comp:36) makes the
+ *     fp32 sums order-dependent and irreproducible.  Canonical order here: cells by
+ *     ascending reference cell index ((cz*gy+cy)*gx+cx, i.e. dz outer, dy, dx inner),
+ *     inside a cell ascending particle index.  The shader's own dx->dy->dz nesting
+ *     is not observable in its output because list order inside a cell is already
+ *     arbitrary.
+ *  3. pow().  pow(h,9), pow(h,6), pow(x,3.0), pow(x,2.0) are exact products.
+ *  4. Division, sqrt: IEEE-754 correctly rounded fp32.
+ *  5. Contraction.  GLSL lets the compiler fuse a*b+c.  Fixed here: dot products are
+ *     fma(z,z', fma(y,y', x*x')); accumulations `s += a*b` are fmaf(a,b,s); every
+ *     other operation is a separately rounded fp32 op (build with -ffp-contract=off).
+ *  6. sin() in WaveImpulse: a fully specified fp32 routine (o_sinf) so that the HIP
+ *     kernel can match bit for bit; max error about 1 ulp for |x| < 1e4.
+ *  7. RNG for spawn jitter: PCG32 (the reference seeds default_random_engine with
+ *     time(nullptr), SPHFluid3D.cpp:99, which is neither reproducible nor portable).
+ *  8. Float -> cell index: clamp in float then convert (identical for in-range
+ *     values; avoids undefined float->int overflow for far-away particles).
+ *  9. Reciprocal forms.  GLSL specifies a/b only to 2.5 ULP and drivers lower it to
+ *     a*rcp(b); two divisions of the force sweep are fixed in that form so they can be
+ *     hoisted per neighbour / per pair: `rij / r` (SPHFluid.comp:54) is rij * (1/r) and
+ *     `x / (2.0 * pj.density)` (:137) is x * (1/(2 rho_j)), each reciprocal a correctly
+ *     rounded fp32 division.  Every other division is written as in the shader.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    float pos[4];
+    float vel[4];
+    float acc[4];
+    float density, pressure, padA, padB;
+    int32_t isGhost, isActive, padC, pad0;
+} OParticle; /* 80 bytes, SPHFluid3D.h:12-24 */
+
+typedef struct {
+    float h, mass, restDensity, gasConstant, viscosity;      /* SPHFluid3D.h:94-98 */
+    float gravity[3];                                        /* :99-101 (X,Y,Z)    */
+    float surfaceTension, timeStep;                          /* :102-103           */
+    int32_t pause;                                           /* :104               */
+    int32_t useJitter; float jitterAmp;                      /* :106-107           */
+    float foamGen, foamVelRef;                               /* :109-110           */
+    float boxCenter[3], boxHalf[3], boxEulerDeg[3];          /* :112-116           */
+    int32_t shapeType; float shapeAux[3];                    /* :117-119           */
+    int32_t mixPattern, dyePattern;                          /* :121-122           */
+    float wallRestitution, wallFriction;                     /* :123-124           */
+    int32_t gridCap;                                         /* 160 in the reference, SPHFluid3D.cpp:370 */
+} OParams;
+
+typedef struct {
+    int32_t dims[3];
+    int32_t numCells;
+    float gridMin[3];
+    float cellSize;
+} OGrid;
+
+#define O_PI_F 3.141592653589f /* literal used by SPHFluid.comp:45,53,60 */
+
+int sph_oracle_sizeof_particle(void) { return (int)sizeof(OParticle); }
+int sph_oracle_sizeof_params(void) { return (int)sizeof(OParams); }
+
+void sph_oracle_default_params(OParams* p) {
+    memset(p, 0, sizeof(*p));
+    p->h = 0.28f; p->mass = 13.8f; p->restDensity = 1000.0f; p->gasConstant = 2000.0f;
+    p->viscosity = 3.5f; p->gravity[0] = 0.0f; p->gravity[1] = -980.0f; p->gravity[2] = 0.0f;
+    p->surfaceTension = 0.0728f; p->timeStep = 0.001f; p->pause = 0;
+    p->useJitter = 1; p->jitterAmp = 0.20f; p->foamGen = 1.0f; p->foamVelRef = 8.0f;
+    p->boxHalf[0] = p->boxHalf[1] = p->boxHalf[2] = 7.0f;
+    p->shapeType = 0; p->shapeAux[0] = 5.0f; p->shapeAux[1] = 0.35f; p->shapeAux[2] = 2.5f;
+    p->mixPattern = 0; p->dyePattern = 0;
+    p->wallRestitution = 0.15f; p->wallFriction = 0.02f;
+    p->gridCap = 160;
+}
+
+/* ---------------------------------------------------------------- helpers */
+
+static inline float o_dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+static inline float o_clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static inline float o_signf(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+/* Fully specified fp32 sine (semantic 6).  Cody-Waite reduction by pi/2 in three
+ * parts, then degree-7 / degree-6 minimax-style polynomials on [-pi/4, pi/4]. */
+float sph_oracle_sinf(float x) {
+    const float TWO_OVER_PI = 0.636619772367581343f;
+    const float P1 = 1.5703125f;                 /* pi/2 split, 8+ trailing zero bits each */
+    const float P2 = 4.837512969970703125e-4f;
+    const float P3 = 7.549789948768648e-8f;
+    float q = rintf(x * TWO_OVER_PI);
+    float r = fmaf(q, -P1, x);
+    r = fmaf(q, -P2, r);
+    r = fmaf(q, -P3, r);
+    /* quadrant = q mod 4 computed in float: no float->int overflow for huge |x| */
+    int n = (int)(q - 4.0f * floorf(q * 0.25f));
+    float r2 = r * r;
+    float res;
+    if (n & 1) { /* cos(r) */
+        float c = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+        c = fmaf(c, r2, 4.166664568298827e-2f);
+        c = fmaf(c, r2, -0.5f);
+        res = fmaf(c, r2, 1.0f);
+    } else {     /* sin(r) */
+        float s = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+        s = fmaf(s, r2, -1.6666654611e-1f);
+        s = s * r2;
+        res = fmaf(s, r, r);
+    }
+    return (n & 2) ? -res : res;
+}
+
+/* MakeRotationMat3XYZ, SPHFluid3D.cpp:13-30: column-major world_from_box R = Rz*Ry*Rx. */
+static void o_rotation(const float eulerDeg[3], float outM[9]) {
+    const float k = (float)(3.14159265358979323846 / 180.0); /* M_PI */
+    const float rx = eulerDeg[0] * k, ry = eulerDeg[1] * k, rz = eulerDeg[2] * k;
+    const float cx = cosf(rx), sx = sinf(rx);
+    const float cy = cosf(ry), sy = sinf(ry);
+    const float cz = cosf(rz), sz = sinf(rz);
+    const float Rz[9] = { cz, sz, 0, -sz, cz, 0, 0, 0, 1 };
+    const float Ry[9] = { cy, 0, -sy, 0, 1, 0, sy, 0, cy };
+    const float Rx[9] = { 1, 0, 0, 0, cx, sx, 0, -sx, cx };
+    float Rzy[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r)
+            Rzy[c * 3 + r] = Rz[0 * 3 + r] * Ry[c * 3 + 0] + Rz[1 * 3 + r] * Ry[c * 3 + 1] + Rz[2 * 3 + r] * Ry[c * 3 + 2];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r)
+            outM[c * 3 + r] = Rzy[0 * 3 + r] * Rx[c * 3 + 0] + Rzy[1 * 3 + r] * Rx[c * 3 + 1] + Rzy[2 * 3 + r] * Rx[c * 3 + 2];
+}
+void sph_oracle_rotation(const float eulerDeg[3], float outM[9]) { o_rotation(eulerDeg, outM); }
+
+/* EffectiveHalf, SPHFluid3D.h:127-158 */
+void sph_oracle_effective_half(const OParams* p, float out[3]) {
+    const float bx = p->boxHalf[0], by = p->boxHalf[1], bz = p->boxHalf[2];
+    const float ax = p->shapeAux[0], ay = p->shapeAux[1];
+    switch (p->shapeType) {
+    case 1: out[0] = bx; out[1] = bx; out[2] = bx; break;
+    case 2: case 5: case 6: case 7: case 8: out[0] = bx; out[1] = by; out[2] = bx; break;
+    case 3: out[0] = bx + by; out[1] = by; out[2] = bx + by; break;
+    case 4: out[0] = bx; out[1] = by + bx; out[2] = bx; break;
+    case 9: out[0] = 3.0f * bx + by; out[1] = 0.35f * bx + by; out[2] = 3.0f * bx + by; break;
+    case 10: out[0] = bx + by; out[1] = by + ax; out[2] = bx + by; break;
+    case 11: case 14: out[0] = bx + by; out[1] = ay + by; out[2] = bx + by; break;
+    case 12: out[0] = bx + by; out[1] = 1.15f * bx + by; out[2] = by + 0.3f; break;
+    case 13: out[0] = bx; out[1] = bx; out[2] = bx; break;
+    default: out[0] = bx; out[1] = by; out[2] = bz; break;
+    }
+}
+
+/* ComputeGridExtents, SPHFluid3D.cpp:354-376 */
+void sph_oracle_grid_extents(const OParams* p, OGrid* g) {
+    float R[9], half[3], ext[3];
+    g->cellSize = p->h;
+    o_rotation(p->boxEulerDeg, R);
+    sph_oracle_effective_half(p, half);
+    for (int i = 0; i < 3; ++i) {
+        ext[i] = fabsf(R[i]) * half[0] + fabsf(R[3 + i]) * half[1] + fabsf(R[6 + i]) * half[2];
+        ext[i] = ext[i] + g->cellSize;
+        g->gridMin[i] = p->boxCenter[i] - ext[i];
+        int d = (int)ceilf((2.0f * ext[i]) / g->cellSize);
+        if (d < 1) d = 1;
+        if (d > p->gridCap) d = p->gridCap;
+        g->dims[i] = d;
+    }
+    int nc = g->dims[0] * g->dims[1] * g->dims[2];
+    g->numCells = nc < 1 ? 1 : nc;
+}
+
+/* BuildGrid.comp:21-31: cell coordinate of a position */
+static inline void o_cell_coord(const OGrid* g, const float pos[3], int c[3]) {
+    for (int a = 0; a < 3; ++a) {
+        float q = (pos[a] - g->gridMin[a]) / g->cellSize;
+        float f = floorf(q);
+        f = fminf(fmaxf(f, 0.0f), (float)(g->dims[a] - 1));
+        c[a] = (int)f;
+    }
+}
+static inline int o_flatten(const OGrid* g, const int c[3]) {
+    return (c[2] * g->dims[1] + c[1]) * g->dims[0] + c[0];
+}
+
+/* ClearGrid.comp + BuildGrid.comp restated as a stable counting sort:
+ * cellStart[C+1] exclusive prefix, sorted[N] = particle indices grouped by cell in
+ * ascending particle index (canonical order 2), particleCell[N] = flattened cell.
+ * Also (optionally) the shader's own linked list for ONE legal arrival order
+ * (ascending i => each list is in descending index order). */
+void sph_oracle_build_grid(const OParticle* P, int n, const OGrid* g,
+                           int32_t* cellStart, int32_t* sorted, int32_t* particleCell,
+                           int32_t* cellHead /*nullable*/, int32_t* particleNext /*nullable*/) {
+    const int C = g->numCells;
+    memset(cellStart, 0, sizeof(int32_t) * (size_t)(C + 1));
+    for (int i = 0; i < n; ++i) {
+        int c[3];
+        o_cell_coord(g, P[i].pos, c);
+        int cell = o_flatten(g, c);
+        particleCell[i] = cell;
+        cellStart[cell + 1]++;
+    }
+    for (int c = 0; c < C; ++c) cellStart[c + 1] += cellStart[c];
+    int32_t* cursor = (int32_t*)malloc(sizeof(int32_t) * (size_t)(C > 0 ? C : 1));
+    memcpy(cursor, cellStart, sizeof(int32_t) * (size_t)C);
+    for (int i = 0; i < n; ++i) sorted[cursor[particleCell[i]]++] = i;
+    free(cursor);
+    if (cellHead && particleNext) {
+        for (int c = 0; c < C; ++c) cellHead[c] = -1;            /* ClearGrid.comp:9 */
+        for (int i = 0; i < n; ++i) {                            /* BuildGrid.comp:23-37 */
+            int cell = particleCell[i];
+            particleNext[i] = cellHead[cell];
+            cellHead[cell] = i;
+        }
+    }
+}
+
+typedef struct {
+    float h, h2, poly6C, spikyC, viscC;
+    float mass, restDensity, gasConstant, viscosity, surfaceTension;
+    float g[3];
+    float dt, maxSpeed, foamGen, foamVelRef;
+} OConsts;
+
+static void o_consts(const OParams* p, float dt, OConsts* k) {
+    const float h = p->h;
+    const float h2 = h * h;
+    const float h3 = h2 * h;
+    const float h6 = h3 * h3;
+    const float h9 = h6 * h3;
+    k->h = h; k->h2 = h2;
+    k->poly6C = 315.0f / ((64.0f * O_PI_F) * h9);   /* SPHFluid.comp:45 */
+    k->spikyC = -45.0f / (O_PI_F * h6);             /* :53 */
+    k->viscC = 45.0f / (O_PI_F * h6);               /* :60 */
+    k->mass = p->mass; k->restDensity = p->restDensity; k->gasConstant = p->gasConstant;
+    k->viscosity = p->viscosity; k->surfaceTension = p->surfaceTension;
+    k->g[0] = p->gravity[0]; k->g[1] = p->gravity[1]; k->g[2] = p->gravity[2];
+    k->dt = dt;
+    k->maxSpeed = (0.4f * p->h) / fmaxf(dt, 1e-6f); /* SPHFluid3D.cpp:488 */
+    k->foamGen = p->foamGen; k->foamVelRef = p->foamVelRef;
+}
+
+/* SPHFluid.comp main(), :66-221, for particle i, snapshot semantics. */
+static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g,
+                      const int32_t* cellStart, const int32_t* sorted, const OConsts* k) {
+    OParticle pi = in[i];
+    if (pi.isGhost == 1) {                                   /* :72-83 */
+        if (pi.isActive == 0) { out[i] = pi; return; }
+        pi.vel[0] = pi.vel[1] = pi.vel[2] = pi.vel[3] = 0.0f;
+        pi.acc[0] = pi.acc[1] = pi.acc[2] = pi.acc[3] = 0.0f;
+        pi.density = k->restDensity;
+        pi.pressure = 0.0f;
+        out[i] = pi;
+        return;
+    }
+    int cc[3];
+    o_cell_coord(g, pi.pos, cc);                             /* :85-87 */
+    const int gx = g->dims[0], gy = g->dims[1], gz = g->dims[2];
+    const float h = k->h, h2 = k->h2, mass = k->mass;
+
+    /* ---- sweep 1: density, :90-106 (self included) ---- */
+    float density = 0.0f;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
+        int cell = (nz * gy + ny) * gx + nx;
+        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+            const OParticle* pj = &in[sorted[q]];
+            float ddx = pi.pos[0] - pj->pos[0], ddy = pi.pos[1] - pj->pos[1], ddz = pi.pos[2] - pj->pos[2];
+            float r2 = o_dot3(ddx, ddy, ddz, ddx, ddy, ddz);
+            if (r2 < h2) {
+                float t = h2 - r2;
+                float w = k->poly6C * ((t * t) * t);
+                density = fmaf(mass, w, density);
+            }
+        }
+    }
+    density = fmaxf(density, k->restDensity * 0.5f);
+    pi.density = density;
+    pi.pressure = fmaxf(k->gasConstant * (pi.density - k->restDensity), 0.0f);   /* :111 */
+
+    /* ---- sweep 2: forces, :113-155 (self skipped) ---- */
+    float fP[3] = { 0, 0, 0 }, fV[3] = { 0, 0, 0 }, gradC[3] = { 0, 0, 0 };
+    float lapC = 0.0f;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
+        int cell = (nz * gy + ny) * gx + nx;
+        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+            int j = sorted[q];
+            if (j == i) continue;
+            const OParticle* pj = &in[j];
+            float rij[3] = { pi.pos[0] - pj->pos[0], pi.pos[1] - pj->pos[1], pi.pos[2] - pj->pos[2] };
+            float r = sqrtf(o_dot3(rij[0], rij[1], rij[2], rij[0], rij[1], rij[2]));
+            if (r < h && pj->density > 0.0f) {
+                float gW[3] = { 0, 0, 0 };                   /* spikyGrad :50-57 */
+                if (r > 0.0f) {
+                    float hr = h - r;
+                    float s = k->spikyC * (hr * hr);
+                    float invr = 1.0f / r;                   /* semantic 9: rij / r */
+                    gW[0] = s * (rij[0] * invr); gW[1] = s * (rij[1] * invr); gW[2] = s * (rij[2] * invr);
+                }
+                float i2r = 1.0f / (2.0f * pj->density);     /* semantic 9: x / (2.0 * rho_j) */
+                float pterm = ((-mass) * (pi.pressure + pj->pressure)) * i2r;
+                float mor = mass / pj->density;
+                float lapW = k->viscC * (h - r);             /* viscLaplacian :58-64 */
+                for (int a = 0; a < 3; ++a) {
+                    fP[a] = fmaf(gW[a], pterm, fP[a]);
+                    fV[a] = fmaf((pj->vel[a] - pi.vel[a]) * mor, lapW, fV[a]);
+                    gradC[a] = fmaf(mor, gW[a], gradC[a]);
+                }
+                lapC = fmaf(mor, lapW, lapC);
+                /* `c += mj_over_rhoj * w` (:148) feeds nothing and is omitted. */
+            }
+        }
+    }
+    float fS[3] = { 0, 0, 0 };                               /* :157-163 */
+    float gl = sqrtf(o_dot3(gradC[0], gradC[1], gradC[2], gradC[0], gradC[1], gradC[2]));
+    if (gl > 1e-6f) {
+        float sc = (-k->surfaceTension) * lapC;
+        for (int a = 0; a < 3; ++a) fS[a] = sc * (gradC[a] / gl);
+    }
+    for (int a = 0; a < 3; ++a) {                            /* :165-171 */
+        float fG = k->g[a] * pi.density;
+        float t = fmaf(k->viscosity, fV[a], fP[a]);
+        t = t + fG;
+        t = t + fS[a];
+        float acc = t / pi.density;
+        pi.acc[a] = acc;
+        pi.vel[a] = fmaf(acc, k->dt, pi.vel[a]);
+        pi.vel[a] = pi.vel[a] * 0.995f;
+        pi.pos[a] = fmaf(pi.vel[a], k->dt, pi.pos[a]);
+    }
+    pi.acc[3] = 0.0f;
+
+    /* ---- sweep 3: XSPH, :177-201 (own state updated, neighbours at entry,
+     *      cell coordinate NOT recomputed) ---- */
+    float xs[3] = { 0, 0, 0 };
+    float norm = 0.0f;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
+        int cell = (nz * gy + ny) * gx + nx;
+        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+            int j = sorted[q];
+            if (j == i) continue;
+            const OParticle* pj = &in[j];
+            float ddx = pi.pos[0] - pj->pos[0], ddy = pi.pos[1] - pj->pos[1], ddz = pi.pos[2] - pj->pos[2];
+            float r2 = o_dot3(ddx, ddy, ddz, ddx, ddy, ddz);
+            if (r2 < h2 && pj->density > 0.0f) {
+                float t = h2 - r2;
+                float w = k->poly6C * ((t * t) * t);
+                float mor = mass / pj->density;
+                for (int a = 0; a < 3; ++a) xs[a] = fmaf((pj->vel[a] - pi.vel[a]) * w, mor, xs[a]);
+                norm = norm + w;
+            }
+        }
+    }
+    if (norm > 0.0f) { xs[0] = xs[0] / norm; xs[1] = xs[1] / norm; xs[2] = xs[2] / norm; }
+    for (int a = 0; a < 3; ++a) pi.vel[a] = fmaf(0.12f, xs[a], pi.vel[a]);
+
+    {                                                        /* velocity cap :203-207 */
+        float sp = sqrtf(o_dot3(pi.vel[0], pi.vel[1], pi.vel[2], pi.vel[0], pi.vel[1], pi.vel[2]));
+        if (sp > k->maxSpeed) {
+            float f = k->maxSpeed / sp;
+            pi.vel[0] = pi.vel[0] * f; pi.vel[1] = pi.vel[1] * f; pi.vel[2] = pi.vel[2] * f;
+        }
+    }
+    {                                                        /* foam :209-217 */
+        float speed = sqrtf(o_dot3(pi.vel[0], pi.vel[1], pi.vel[2], pi.vel[0], pi.vel[1], pi.vel[2]));
+        float aer = o_clampf((k->restDensity - pi.density) / k->restDensity, 0.0f, 1.0f)
+                  * o_clampf(speed / fmaxf(k->foamVelRef, 1e-3f), 0.0f, 1.0f);
+        pi.padA = fmaxf(aer * k->foamGen, pi.padA * 0.995f);
+    }
+    out[i] = pi;                                             /* :220 */
+}
+
+/* OBBConstraints.comp, box branch :297-309 and response :311-330.  Other shape
+ * types are handled by sph_oracle_obb_shape() below. */
+typedef struct {
+    float R[9];
+    float c[3], half[3], aux[3];
+    float e, f;
+    int shape;
+} OObb;
+
+static void o_obb_setup(const OParams* p, OObb* b) {
+    o_rotation(p->boxEulerDeg, b->R);                        /* SPHFluid3D.cpp:498-506 */
+    for (int a = 0; a < 3; ++a) { b->c[a] = p->boxCenter[a]; b->half[a] = p->boxHalf[a]; b->aux[a] = p->shapeAux[a]; }
+    b->e = p->wallRestitution; b->f = p->wallFriction; b->shape = p->shapeType;
+}
+
+static inline void o_matvec(const float R[9], const float v[3], float out[3]) {
+    for (int i = 0; i < 3; ++i) out[i] = fmaf(R[6 + i], v[2], fmaf(R[3 + i], v[1], R[i] * v[0]));
+}
+
+/* Shape projection: returns hit, fills qL and nL (local space). */
+static int o_shape_project(const OObb* b, const float pL[3], float qL[3], float nL[3]);
+
+static void o_obb_one(OParticle* p, const OObb* b) {
+    if (p->isGhost != 0) return;                             /* :46 */
+    float d[3] = { p->pos[0] - b->c[0], p->pos[1] - b->c[1], p->pos[2] - b->c[2] };
+    float pL[3];                                             /* worldToLocal :32-36 */
+    for (int a = 0; a < 3; ++a) pL[a] = o_dot3(d[0], d[1], d[2], b->R[3 * a], b->R[3 * a + 1], b->R[3 * a + 2]);
+    float qL[3] = { pL[0], pL[1], pL[2] }, nL[3] = { 0, 0, 0 };
+    int hit = o_shape_project(b, pL, qL, nL);
+    if (hit) {                                               /* :311-327 */
+        float nW[3], t[3];
+        o_matvec(b->R, nL, nW);
+        float len = sqrtf(o_dot3(nW[0], nW[1], nW[2], nW[0], nW[1], nW[2]));
+        nW[0] = nW[0] / len; nW[1] = nW[1] / len; nW[2] = nW[2] / len;
+        o_matvec(b->R, qL, t);
+        for (int a = 0; a < 3; ++a) p->pos[a] = b->c[a] + t[a];
+        float vn = o_dot3(p->vel[0], p->vel[1], p->vel[2], nW[0], nW[1], nW[2]);
+        for (int a = 0; a < 3; ++a) {
+            float vN = vn * nW[a];
+            float vT = p->vel[a] - vN;
+            float vNn = (-b->e) * vN;
+            float vTn = (1.0f - b->f) * vT;
+            p->vel[a] = vNn + vTn;
+        }
+    }
+}
+
+static int o_shape_project(const OObb* b, const float pL[3], float qL[3], float nL[3]) {
+    const float hx = b->half[0], hy = b->half[1], hz = b->half[2];
+    switch (b->shape) {
+    case 1: {                                                /* sphere :60-68 */
+        float R = hx;
+        float d = sqrtf(o_dot3(pL[0], pL[1], pL[2], pL[0], pL[1], pL[2]));
+        if (d > R) {
+            if (d > 1e-6f) { nL[0] = pL[0] / d; nL[1] = pL[1] / d; nL[2] = pL[2] / d; }
+            else { nL[0] = 0; nL[1] = 1; nL[2] = 0; }
+            qL[0] = nL[0] * R; qL[1] = nL[1] * R; qL[2] = nL[2] * R;
+            return 1;
+        }
+        return 0;
+    }
+    case 2: {                                                /* cylinder :69-82 */
+        float R = hx, H = hy;
+        float rad = sqrtf(fmaf(pL[2], pL[2], pL[0] * pL[0]));
+        float qx = pL[0], qz = pL[2];
+        if (rad > R) { float s = R / fmaxf(rad, 1e-6f); qx = pL[0] * s; qz = pL[2] * s; }
+        qL[0] = qx; qL[1] = o_clampf(pL[1], -H, H); qL[2] = qz;
+        float de[3] = { pL[0] - qL[0], pL[1] - qL[1], pL[2] - qL[2] };
+        float dl = sqrtf(o_dot3(de[0], de[1], de[2], de[0], de[1], de[2]));
+        if (dl > 1e-6f) { nL[0] = de[0] / dl; nL[1] = de[1] / dl; nL[2] = de[2] / dl; return 1; }
+        return 0;
+    }
+    case 3: {                                                /* torus :83-97 */
+        float R = hx, r = hy;
+        float lxz = sqrtf(fmaf(pL[2], pL[2], pL[0] * pL[0]));
+        float rdx = 1.0f, rdz = 0.0f;
+        if (lxz > 1e-6f) { rdx = pL[0] / lxz; rdz = pL[2] / lxz; }
+        float ring[3] = { rdx * R, 0.0f, rdz * R };
+        float d[3] = { pL[0] - ring[0], pL[1] - ring[1], pL[2] - ring[2] };
+        float dl = sqrtf(o_dot3(d[0], d[1], d[2], d[0], d[1], d[2]));
+        if (dl > r) {
+            float m = fmaxf(dl, 1e-6f);
+            for (int a = 0; a < 3; ++a) { nL[a] = d[a] / m; qL[a] = ring[a] + nL[a] * r; }
+            return 1;
+        }
+        return 0;
+    }
+    case 4: {                                                /* capsule :98-110 */
+        float R = hx, H = hy;
+        float seg[3] = { 0.0f, o_clampf(pL[1], -H, H), 0.0f };
+        float d[3] = { pL[0] - seg[0], pL[1] - seg[1], pL[2] - seg[2] };
+        float dl = sqrtf(o_dot3(d[0], d[1], d[2], d[0], d[1], d[2]));
+        if (dl > R) {
+            float m = fmaxf(dl, 1e-6f);
+            for (int a = 0; a < 3; ++a) { nL[a] = d[a] / m; qL[a] = seg[a] + nL[a] * R; }
+            return 1;
+        }
+        return 0;
+    }
+    case 5: {                                                /* hourglass :111-129 */
+        float baseR = hx, H = fmaxf(hy, 1e-6f), neckR = fminf(hz, baseR);
+        float yC = o_clampf(pL[1], -H, H);
+        float rMax = neckR + ((baseR - neckR) * fabsf(yC)) / H;
+        float lxz = sqrtf(fmaf(pL[2], pL[2], pL[0] * pL[0]));
+        float qx = pL[0], qz = pL[2];
+        if (lxz > rMax) { float s = rMax / fmaxf(lxz, 1e-6f); qx = pL[0] * s; qz = pL[2] * s; }
+        qL[0] = qx; qL[1] = yC; qL[2] = qz;
+        float de[3] = { pL[0] - qL[0], pL[1] - qL[1], pL[2] - qL[2] };
+        float dl = sqrtf(o_dot3(de[0], de[1], de[2], de[0], de[1], de[2]));
+        if (dl > 1e-6f) { nL[0] = de[0] / dl; nL[1] = de[1] / dl; nL[2] = de[2] / dl; return 1; }
+        return 0;
+    }
+    case 6: {                                                /* egg :130-143 */
+        float a = fmaxf(hx, 1e-6f), bb = fmaxf(hy, 1e-6f);
+        float e[3] = { a, bb, a };
+        float u[3] = { pL[0] / e[0], pL[1] / e[1], pL[2] / e[2] };
+        float d = sqrtf(o_dot3(u[0], u[1], u[2], u[0], u[1], u[2]));
+        if (d > 1.0f) {
+            float gq[3];
+            for (int k = 0; k < 3; ++k) { qL[k] = (u[k] / d) * e[k]; gq[k] = qL[k] / (e[k] * e[k]); }
+            float gl = sqrtf(o_dot3(gq[0], gq[1], gq[2], gq[0], gq[1], gq[2]));
+            for (int k = 0; k < 3; ++k) nL[k] = gq[k] / gl;
+            return 1;
+        }
+        return 0;
+    }
+    default: {                                               /* box :297-309 */
+        qL[0] = o_clampf(pL[0], -hx, hx); qL[1] = o_clampf(pL[1], -hy, hy); qL[2] = o_clampf(pL[2], -hz, hz);
+        float de[3] = { pL[0] - qL[0], pL[1] - qL[1], pL[2] - qL[2] };
+        float d[3] = { fabsf(de[0]), fabsf(de[1]), fabsf(de[2]) };
+        if (d[0] > 0.0f || d[1] > 0.0f || d[2] > 0.0f) {
+            if (d[0] >= d[1] && d[0] >= d[2]) { nL[0] = o_signf(de[0]); nL[1] = 0; nL[2] = 0; }
+            else if (d[1] >= d[0] && d[1] >= d[2]) { nL[0] = 0; nL[1] = o_signf(de[1]); nL[2] = 0; }
+            else { nL[0] = 0; nL[1] = 0; nL[2] = o_signf(de[2]); }
+            return 1;
+        }
+        return 0;
+    }
+    }
+}
+
+/* Shape types this oracle restates exactly (others fall through to box in
+ * o_shape_project and must not be claimed): 0 box, 1 sphere, 2 cylinder, 3 torus,
+ * 4 capsule, 5 hourglass, 6 egg. */
+int sph_oracle_shape_supported(int shape) { return shape >= 0 && shape <= 6; }
+
+void sph_oracle_obb(OParticle* P, int n, const OParams* p) {
+    OObb b;
+    o_obb_setup(p, &b);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) o_obb_one(&P[i], &b);
+}
+
+/* SPH pass only (no OBB): in -> out, snapshot semantics. */
+void sph_oracle_sph_pass(const OParticle* in, OParticle* out, int n, const OParams* p, float overrideDt) {
+    const float dt = (overrideDt > 0.0f) ? overrideDt : p->timeStep;   /* SPHFluid3D.cpp:434 */
+    OGrid g;
+    OConsts k;
+    sph_oracle_grid_extents(p, &g);
+    o_consts(p, dt, &k);
+    int32_t* cellStart = (int32_t*)malloc(sizeof(int32_t) * (size_t)(g.numCells + 1));
+    int32_t* sorted = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int32_t* pcell = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    sph_oracle_build_grid(in, n, &g, cellStart, sorted, pcell, NULL, NULL);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < n; ++i) o_sph_one(i, in, out, &g, cellStart, sorted, &k);
+    free(cellStart); free(sorted); free(pcell);
+}
+
+/* DispatchCompute, SPHFluid3D.cpp:431-509: ClearGrid -> BuildGrid -> SPHFluid -> OBB.
+ * P is updated in place; scratch (n particles) is caller-provided. */
+void sph_oracle_substep(OParticle* P, OParticle* scratch, int n, const OParams* p, float overrideDt) {
+    if (p->pause) return;                                    /* :432 */
+    sph_oracle_sph_pass(P, scratch, n, p, overrideDt);
+    sph_oracle_obb(scratch, n, p);
+    memcpy(P, scratch, sizeof(OParticle) * (size_t)n);
+}
+
+/* ApplyWaveImpulse + WaveImpulse.comp */
+void sph_oracle_wave_impulse(OParticle* P, int n, float amplitude, float wavelength, float phase,
+                             const float dir[3], float yMin, float yMax) {
+    if (amplitude == 0.0f || wavelength <= 1e-6f) return;    /* SPHFluid3D.cpp:607 */
+    float len = sqrtf(o_dot3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]));
+    float nd[3] = { 0.0f, 1.0f, 0.0f };
+    if (len > 1e-6f) { nd[0] = dir[0] / len; nd[1] = dir[1] / len; nd[2] = dir[2] / len; }
+    const float kk = 6.28318530718f / wavelength;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* p = &P[i];
+        if (p->isGhost != 0) continue;
+        if (p->pos[1] < yMin || p->pos[1] > yMax) continue;
+        float theta = fmaf(kk, o_dot3(p->pos[0], p->pos[1], p->pos[2], nd[0], nd[1], nd[2]), phase);
+        float kick = amplitude * sph_oracle_sinf(theta);
+        for (int a = 0; a < 3; ++a) p->vel[a] = fmaf(nd[a], kick, p->vel[a]);
+    }
+}
+
+/* ------------------------------------------------------------------ spawn */
+
+typedef struct { uint64_t state, inc; } OPcg;
+static uint32_t o_pcg_next(OPcg* r) {
+    uint64_t old = r->state;
+    r->state = old * 6364136223846793005ULL + r->inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((32u - rot) & 31u));
+}
+static void o_pcg_seed(OPcg* r, uint64_t seed) {
+    r->state = 0u; r->inc = (54u << 1u) | 1u;
+    o_pcg_next(r); r->state += seed; o_pcg_next(r);
+}
+static float o_pcg_uniform(OPcg* r, float lo, float hi) {
+    float u = (float)(o_pcg_next(r) >> 8) * (1.0f / 16777216.0f);
+    return lo + u * (hi - lo);
+}
+
+/* insideShape lambda, SPHFluid3D.cpp:167-289 (shapes 0..6 restated) */
+static int o_inside_shape(const OParams* p, const float hf[3], float margin, float lx, float ly, float lz) {
+    switch (p->shapeType) {
+    case 1: { float r = hf[0] - margin; return lx * lx + ly * ly + lz * lz <= r * r; }
+    case 2: { float r = hf[0] - margin; return lx * lx + lz * lz <= r * r && fabsf(ly) <= hf[1] - margin; }
+    case 3: { float R = p->boxHalf[0], r = p->boxHalf[1] - margin;
+              float dr = sqrtf(lx * lx + lz * lz) - R;
+              return r > 0.0f && (dr * dr + ly * ly) <= r * r; }
+    case 4: { float r = p->boxHalf[0] - margin, H = p->boxHalf[1];
+              float dy = ly - o_clampf(ly, -H, H);
+              return (lx * lx + lz * lz + dy * dy) <= r * r; }
+    case 5: { float baseR = p->boxHalf[0], H = fmaxf(p->boxHalf[1], 1e-6f);
+              float neckR = fminf(p->boxHalf[2], baseR);
+              if (fabsf(ly) > H - margin) return 0;
+              float rMax = neckR + (baseR - neckR) * fabsf(ly) / H - margin;
+              return rMax > 0.0f && (lx * lx + lz * lz) <= rMax * rMax; }
+    case 6: { float a = fmaxf(p->boxHalf[0] - margin, 1e-4f), b = fmaxf(p->boxHalf[1] - margin, 1e-4f);
+              float u = lx / a, v = ly / b, w = lz / a;
+              return (u * u + v * v + w * w) <= 1.0f; }
+    default: return 1;
+    }
+}
+
+/* InitializeParticles standard fill, SPHFluid3D.cpp:85-102,159-332.
+ * Returns the particle count actually produced (<= nRequested) and writes
+ * param_mass = rho0 * spacing^3 (:92) to *massOut.  Jitter draws: three per lattice
+ * point in x,y,z order, whether or not the point is kept (as in :296-299). */
+int sph_oracle_spawn(const OParams* p, int nRequested, uint32_t seed, OParticle* out, float* massOut) {
+    const float h = p->h;
+    const float spacing = h * 0.85f;
+    *massOut = p->restDensity * spacing * spacing * spacing;
+    const float fillFraction = 0.4f;
+    OPcg rng; o_pcg_seed(&rng, seed);
+    const float jlo = -spacing * p->jitterAmp, jhi = spacing * p->jitterAmp;
+    float hf[3];
+    sph_oracle_effective_half(p, hf);
+    const float margin = spacing * 0.5f;
+    int layersY = (int)((2.0f * hf[1] * fillFraction) / spacing); if (layersY < 1) layersY = 1;
+    int sideX = (int)((hf[0] * 1.7f) / spacing); if (sideX < 1) sideX = 1;
+    int sideZ = (int)((hf[2] * 1.7f) / spacing); if (sideZ < 1) sideZ = 1;
+    int count = 0;
+    for (int x = 0; x < sideX && count < nRequested; ++x)
+        for (int y = 0; y < layersY && count < nRequested; ++y)
+            for (int z = 0; z < sideZ && count < nRequested; ++z) {
+                float jx = p->useJitter ? o_pcg_uniform(&rng, jlo, jhi) : 0.0f;
+                float jy = p->useJitter ? o_pcg_uniform(&rng, jlo, jhi) : 0.0f;
+                float jz = p->useJitter ? o_pcg_uniform(&rng, jlo, jhi) : 0.0f;
+                float lx = -hf[0] * 0.85f + (float)x * spacing + jx;
+                float ly = -hf[1] + spacing + (float)y * spacing + jy;
+                float lz = -hf[2] * 0.85f + (float)z * spacing + jz;
+                if (!o_inside_shape(p, hf, margin, lx, ly, lz)) continue;
+                OParticle q; memset(&q, 0, sizeof(q));
+                q.pos[0] = p->boxCenter[0] + lx; q.pos[1] = p->boxCenter[1] + ly; q.pos[2] = p->boxCenter[2] + lz;
+                switch (p->mixPattern) {                     /* :307-311 */
+                case 1: q.padC = (x + y + z) & 1; break;
+                case 2: q.padC = (int)(o_pcg_next(&rng) & 1u); break;
+                default: q.padC = (lx < 0.0f) ? 0 : 1; break;
+                }
+                float d;                                     /* :316-329 */
+                switch (p->dyePattern) {
+                case 1: d = (ly + hf[1]) / fmaxf(2.0f * hf[1], 1e-3f); break;
+                case 2: { float nn = sinf(lx * 1.3f) * cosf(lz * 1.7f) + sinf(ly * 1.1f + lx * 0.7f);
+                          d = 0.5f + 0.5f * sinf(nn * 2.3f); break; }
+                default: d = 0.5f + 0.5f * sinf(lx * 1.5f); break;
+                }
+                q.padB = o_clampf(d, 0.0f, 1.0f);
+                out[count++] = q;
+            }
+    return count;
+}
+
+/* --------------------------------------------------------- CPU baseline leg */
+
+int sph_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void sph_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
