@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
     ap.add_argument("--neighbor", type=int, default=0, help="0 LDS-tiled (default), 1 global gather")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
+    ap.add_argument("--tile-config", type=int, default=-1, help="LDS/workgroup shape of the tiled pass (engine default if < 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="substeps of the CPU sample (0 = auto, about 10-30 s)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass with per-kernel hipEvents")
@@ -121,6 +122,8 @@ def main():
         rec = None
         n_local, n_total = sim.num_owned(), cfg.n
     sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
+    if args.tile_config >= 0:
+        sim.set_option(104, args.tile_config)
     sim.set_option(pkg.SPH_OPT_AOS_MODE, 0 if args.aos == "eager" else 1)
 
     def barrier():

@@ -79,16 +79,15 @@ __device__ __forceinline__ void finish_density(const SimK& k, Own& o) {
 }
 
 // ---- sweep 2, :113-155: pressure / viscosity / colour field (self skipped by caller) -
-// mor = mass / rho_j and i2r = 1 / (2 rho_j) depend on the neighbour only, so callers may
-// compute them once per staged neighbour instead of once per pair (same bits either way).
-// Reciprocal forms fixed by the engine's numerics contract: `rij / r` of :54 is
-// rij * (1/r), `x / (2.0 * pj.density)` of :137 is x * (1/(2 rho_j)).
+// invRho = 1 / rho_j depends on the neighbour only, so callers may form it once per staged
+// neighbour instead of once per pair (same bits either way).  Reciprocal forms fixed by the
+// numerics contract: mass / rho_j = mass * invRho, x / (2 rho_j) = (x * 0.5) *
+// invRho, rij / r = rij * (1/r).
 __device__ __forceinline__ void pair_force_pre(const SimK& k, Own& o, float jx, float jy, float jz,
-                                               float jvx, float jvy, float jvz, float jrho, float jprs,
-                                               float mor, float i2r) {
+                                               float jvx, float jvy, float jvz, float jprs, float invRho) {
     float dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
     float r = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-    if (r < k.h && jrho > 0.0f) {
+    if (r < k.h) {
         float gx = 0.0f, gy = 0.0f, gz = 0.0f;              // spikyGrad :50-57
         float hr = k.h - r;
         if (r > 0.0f) {
@@ -96,7 +95,8 @@ __device__ __forceinline__ void pair_force_pre(const SimK& k, Own& o, float jx, 
             float s = k.spikyC * (hr * hr);
             gx = s * (dx * invr); gy = s * (dy * invr); gz = s * (dz * invr);
         }
-        float pterm = (k.negMass * (o.prs + jprs)) * i2r;
+        float pterm = ((k.negMass * (o.prs + jprs)) * 0.5f) * invRho;
+        float mor = k.mass * invRho;
         float lapW = k.viscC * hr;                          // viscLaplacian :58-64
         o.fPx = fmaf(gx, pterm, o.fPx); o.fPy = fmaf(gy, pterm, o.fPy); o.fPz = fmaf(gz, pterm, o.fPz);
         o.fVx = fmaf((jvx - o.vx) * mor, lapW, o.fVx);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void pair_force_pre(const SimK& k, Own& o, float jx, 
 }
 __device__ __forceinline__ void pair_force(const SimK& k, Own& o, float jx, float jy, float jz,
                                            float jvx, float jvy, float jvz, float jrho, float jprs) {
-    pair_force_pre(k, o, jx, jy, jz, jvx, jvy, jvz, jrho, jprs, k.mass / jrho, 1.0f / (2.0f * jrho));
+    if (jrho > 0.0f) pair_force_pre(k, o, jx, jy, jz, jvx, jvy, jvz, jprs, 1.0f / jrho);
 }
 
 // ---- :157-171: surface tension, gravity, integrate -----------------------------------
@@ -129,12 +129,13 @@ __device__ __forceinline__ void integrate(const SimK& k, Own& o) {
 
 // ---- sweep 3, :177-201: XSPH against the neighbours' ENTRY state ----------------------
 __device__ __forceinline__ void pair_xsph_pre(const SimK& k, Own& o, float jx, float jy, float jz,
-                                              float jvx, float jvy, float jvz, float jrho, float mor) {
+                                              float jvx, float jvy, float jvz, float invRho) {
     float dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
     float r2 = dot3(dx, dy, dz, dx, dy, dz);
-    if (r2 < k.h2 && jrho > 0.0f) {
+    if (r2 < k.h2) {
         float t = k.h2 - r2;
         float w = k.poly6C * ((t * t) * t);
+        float mor = k.mass * invRho;
         o.xsx = fmaf((jvx - o.vx) * w, mor, o.xsx);
         o.xsy = fmaf((jvy - o.vy) * w, mor, o.xsy);
         o.xsz = fmaf((jvz - o.vz) * w, mor, o.xsz);
@@ -143,7 +144,7 @@ __device__ __forceinline__ void pair_xsph_pre(const SimK& k, Own& o, float jx, f
 }
 __device__ __forceinline__ void pair_xsph(const SimK& k, Own& o, float jx, float jy, float jz,
                                           float jvx, float jvy, float jvz, float jrho) {
-    pair_xsph_pre(k, o, jx, jy, jz, jvx, jvy, jvz, jrho, k.mass / jrho);
+    if (jrho > 0.0f) pair_xsph_pre(k, o, jx, jy, jz, jvx, jvy, jvz, 1.0f / jrho);
 }
 
 // ---- :200-217: XSPH blend, velocity cap, foam; returns the new padA -------------------

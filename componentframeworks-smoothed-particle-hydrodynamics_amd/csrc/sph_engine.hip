@@ -83,9 +83,12 @@ struct SphEngine {
     bool internalValid = false, aosValid = false, accValid = false;
     // grid / sort scratch
     uint32_t *d_cellOf = nullptr, *d_slotOf = nullptr, *d_order = nullptr;
+    uint32_t *d_slowSlots = nullptr, *d_slowCount = nullptr;   // exceptional targets of the tiled pass
     uint2* d_tmp = nullptr;
     uint32_t *d_cellCount = nullptr, *d_cellStart = nullptr, *d_blockSums = nullptr;
     int32_t* d_dbg = nullptr;
+    unsigned long long* d_stamps = nullptr;   // diagnostic tile-kernel counters (SPH_OPT_DEBUG bit 3), one row per tile
+    int stampTiles = 0;
     size_t dbgCap = 0;
     // tile scheduler scratch (sph_tile.h)
     sph::TilePlan tile{};
@@ -144,6 +147,7 @@ void free_particle_buffers(SphEngine* e) {
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
+    dev_free(e->d_slowSlots); dev_free(e->d_slowCount);
     e->cap = 0;
 }
 void free_grid_buffers(SphEngine* e) {
@@ -167,6 +171,8 @@ int alloc_particle_buffers(SphEngine* e, size_t n) {
     if ((rc = dev_alloc(&e->d_slotOf, n))) return rc;
     if ((rc = dev_alloc(&e->d_order, n))) return rc;
     if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
+    if ((rc = dev_alloc(&e->d_slowSlots, n))) return rc;
+    if ((rc = dev_alloc(&e->d_slowCount, 4))) return rc;
     e->cap = n;
     return SPH_OK;
 }
@@ -275,7 +281,17 @@ int dispatch_one(SphEngine* e, float overrideDt) {
             Timed t(e, SPH_K_SPH);
             hipLaunchKernelGGL(k_sph_gather, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, e->d_order, e->d_cellStart, n);
         } else {
-            if ((rc = tile_launch(e->tile, e->stream, k, in, out, e->d_order, e->d_cellStart, n, [&](int cls) { return Timed(e, cls); }))) {
+            if (e->tile.debugFlags & 8) {
+                const int nt = tile_count(e->tile, k);
+                if (nt > e->stampTiles) {
+                    dev_free(e->d_stamps);
+                    if ((rc = dev_alloc(&e->d_stamps, (size_t)nt * sph::TS_COUNT))) return rc;
+                    e->stampTiles = nt;
+                    HIP_TRY(hipMemsetAsync(e->d_stamps, 0, sizeof(unsigned long long) * sph::TS_COUNT * (size_t)nt, e->stream));
+                }
+            }
+            SlowQueue sq{e->d_slowCount, e->d_slowSlots};
+            if ((rc = tile_launch(e->tile, e->stream, k, in, out, e->d_order, e->d_cellStart, sq, e->d_stamps, [&](int cls) { return Timed(e, cls); }))) {
                 return fail(SPH_ERR_HIP, "tiled SPH pass failed: %s", hipGetErrorString((hipError_t)(-rc)));
             }
         }
@@ -378,6 +394,7 @@ int sph_destroy(SphEngine* e) {
     free_particle_buffers(e);
     free_grid_buffers(e);
     dev_free(e->d_dbg);
+    dev_free(e->d_stamps);
     for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -420,10 +437,14 @@ int sph_set_option(SphEngine* e, int option, int value) {
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
     case SPH_OPT_DEBUG: e->tile.debugFlags = value; break;
+    case SPH_OPT_TILE_CONFIG:
+        if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value");
+        e->tile.config = value; e->tile.tx = 8; e->tile.ty = 4; e->tile.tz = (value == 1) ? 3 : 4;
+        break;
     case SPH_OPT_TILE_X: case SPH_OPT_TILE_Y: case SPH_OPT_TILE_Z: {
         int tx = e->tile.tx, ty = e->tile.ty, tz = e->tile.tz;
         (option == SPH_OPT_TILE_X ? tx : option == SPH_OPT_TILE_Y ? ty : tz) = value;
-        if (value < 1 || (ty + 2) * (tz + 2) > sph::kMaxRows || (tx + 2) * (ty + 2) * (tz + 2) > sph::kMaxHaloCells)
+        if (value < 1 || (ty + 2) * (tz + 2) > sph::kMaxRows || (tx + 2) * (ty + 2) * (tz + 2) > sph::kMaxHaloCells || tx * ty > sph::kMaxCells)
             return fail(SPH_ERR_ARG, "tile %dx%dx%d exceeds the kernel's LDS tables", tx, ty, tz);
         e->tile.tx = tx; e->tile.ty = ty; e->tile.tz = tz;
         break;
@@ -440,6 +461,7 @@ int sph_get_option(const SphEngine* e, int option, int* value) {
     case SPH_OPT_AOS_MODE: *value = e->optAos; break;
     case SPH_OPT_TIMING: *value = e->optTiming; break;
     case SPH_OPT_DEBUG: *value = e->tile.debugFlags; break;
+    case SPH_OPT_TILE_CONFIG: *value = e->tile.config; break;
     case SPH_OPT_TILE_X: *value = e->tile.tx; break;
     case SPH_OPT_TILE_Y: *value = e->tile.ty; break;
     case SPH_OPT_TILE_Z: *value = e->tile.tz; break;
@@ -545,6 +567,20 @@ int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* 
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    if (count > (int)sph::TS_COUNT) count = (int)sph::TS_COUNT;
+    for (int i = 0; i < count; ++i) out[i] = 0;
+    if (!e->d_stamps || e->stampTiles == 0) return SPH_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<unsigned long long> host((size_t)e->stampTiles * sph::TS_COUNT);
+    HIP_TRY(hipMemcpy(host.data(), e->d_stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int t = 0; t < e->stampTiles; ++t)
+        for (int i = 0; i < count; ++i) out[i] += host[(size_t)t * sph::TS_COUNT + i];
+    if (reset) HIP_TRY(hipMemset(e->d_stamps, 0, host.size() * sizeof(unsigned long long)));
     return SPH_OK;
 }
 

@@ -41,17 +41,36 @@ __global__ __launch_bounds__(kBlock) void k_import(const SphParticle* __restrict
 }
 
 // ---- BuildGrid.comp:21-31: cell of every particle + histogram -------------------------
+// The state is (nearly) cell-sorted from the previous substep, so equal cells sit in adjacent
+// lanes: each run of equal cells inside a wave issues ONE returning atomic (run leader) and
+// hands out consecutive slots, instead of one contended atomic per particle.
 __global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict__ pos, uint32_t* __restrict__ cellOf,
                                                 uint32_t* __restrict__ slotOf, uint32_t* __restrict__ cellCount, int n) {
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float4 p = pos[i];
-    int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
-    int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
-    int cz = cell_axis(p.z, k.gminz, k.cellSize, k.gz);
-    uint32_t cell = (uint32_t)((cz * k.gy + cy) * k.gx + cx);   // flatten(), BuildGrid.comp:19
-    cellOf[i] = cell;
-    slotOf[i] = atomicAdd(&cellCount[cell], 1u);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    uint32_t cell = 0xFFFFFFFFu;
+    if (valid) {
+        const float4 p = pos[i];
+        const int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
+        const int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
+        const int cz = cell_axis(p.z, k.gminz, k.cellSize, k.gz);
+        cell = (uint32_t)((cz * k.gy + cy) * k.gx + cx);   // flatten(), BuildGrid.comp:19
+    }
+    const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+    const bool head = (lane == 0) || (cell != prev);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = (2ull << lane) - 1ull;              // bits 0..lane
+    const int startLane = 63 - __clzll((long long)(heads & upto));
+    const unsigned long long above = heads & ~upto;
+    const int endLane = above ? (__ffsll((long long)above) - 1) : 64;
+    uint32_t base = 0;
+    if (head && valid) base = atomicAdd(&cellCount[cell], (uint32_t)(endLane - lane));
+    base = (uint32_t)__shfl((int)base, startLane, 64);
+    if (valid) {
+        cellOf[i] = cell;
+        slotOf[i] = base + (uint32_t)(lane - startLane);
+    }
 }
 
 // ---- exclusive scan over the histogram -------------------------------------------------

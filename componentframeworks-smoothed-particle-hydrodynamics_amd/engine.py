@@ -69,7 +69,10 @@ ABI_SYMBOLS = (
     "sph_set_option", "sph_get_option", "sph_dispatch", "sph_dispatch_n", "sph_apply_wave_impulse",
     "sph_num_particles", "sph_grid_info", "sph_upload_particles", "sph_download_particles",
     "sph_device_particles", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
+    "sph_debug_counters",
 )
+STAMP_NAMES = ("prologue", "stage", "lists", "scan", "sweep2", "sweep3", "epilogue", "total", "tiles", "slices", "waverounds",
+               "scangroups", "overflow_slices", "slow_lanes", "targets", "candidates", "walk2max", "walk2sum", "rescan_lanes")
 
 
 class SphError(RuntimeError):
@@ -123,6 +126,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_download_grid.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
     L.sph_sync.argtypes = [vp]
     L.sph_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    L.sph_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_int]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version"):
@@ -319,6 +323,11 @@ class SPHFluidGPU:
         cnt = (C.c_int64 * len(KERNEL_CLASSES))()
         _check(self._L.sph_kernel_times(self._h, ms, cnt, 1 if reset else 0))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def debug_counters(self, reset: bool = False) -> dict:
+        buf = (C.c_uint64 * len(STAMP_NAMES))()
+        _check(self._L.sph_debug_counters(self._h, buf, len(STAMP_NAMES), 1 if reset else 0))
+        return {k: int(buf[i]) for i, k in enumerate(STAMP_NAMES)}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -105,10 +105,12 @@ enum {
     SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
     SPH_OPT_TIMING = 4,          /* hipEvents around kernels for sph_kernel_times(): 1 = every kernel, 2 = only the SPH pass */
     /* test / tuning hooks */
-    SPH_OPT_DEBUG = 100,         /* bit 0: force neighbour-list overflow, bit 1: force the sweep-3 re-scan, bit 2: force tile overflow */
+    SPH_OPT_DEBUG = 100,         /* bit 0: force neighbour-list overflow, bit 1: force the sweep-3 re-scan, bit 2: force tile overflow,
+                                    bit 3: diagnostic build of the tiled pass with per-phase cycle counters (sph_debug_counters) */
     SPH_OPT_TILE_X = 101,        /* tile size in cells of the LDS-tiled pass (defaults 8 x 4 x 4) */
     SPH_OPT_TILE_Y = 102,
-    SPH_OPT_TILE_Z = 103
+    SPH_OPT_TILE_Z = 103,
+    SPH_OPT_TILE_CONFIG = 104    /* LDS budget / workgroup shape of the tiled pass: 0 = 53 KB x 256 thr, 1 = 38 KB x 256 thr, 2 = 53 KB x 320 thr */
 };
 
 /* ---- host-only helpers (no device needed) --------------------------------------- */
@@ -175,6 +177,9 @@ int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n);
  * particleCell[n] (binding 3) in the reference's cell indexing. Synchronises. */
 int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* particleCell, size_t n);
 int sph_sync(SphEngine* e);
+/* Diagnostic counters of the tiled pass (SPH_OPT_DEBUG bit 3): per-phase shader-clock sums and
+ * tile statistics, in the order of enum TileStamp in csrc/sph_tile.h.  Never used on a timed path. */
+int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset);
 
 /* ---- measurement ----------------------------------------------------------------- */
 enum {

@@ -316,9 +316,9 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
             s = (spikyC * (hr * hr).astype(_F)).astype(_F)
             invr = (_F(1.0) / r).astype(_F)
             gW = np.where((r > 0)[:, None], (s[:, None] * (d * invr[:, None]).astype(_F)).astype(_F), _F(0)).astype(_F)
-            i2r = (_F(1.0) / (_F(2.0) * rj).astype(_F)).astype(_F)
-            pterm = (((-mass) * (prs + prs_in[jj]).astype(_F)).astype(_F) * i2r).astype(_F)
-            mor = (mass / rj).astype(_F)
+            inv_rho = (_F(1.0) / rj).astype(_F)
+            pterm = ((((-mass) * (prs + prs_in[jj]).astype(_F)).astype(_F) * _F(0.5)).astype(_F) * inv_rho).astype(_F)
+            mor = (mass * inv_rho).astype(_F)
             lapW = (viscC * hr).astype(_F)
             for a in range(3):
                 fP[:, a] = np.where(acc, _fma(gW[:, a], pterm, fP[:, a]), fP[:, a])
@@ -357,7 +357,7 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
             acc = ok & (r2 < h2) & (rj > 0)
             t = (h2 - r2).astype(_F)
             w = (poly6C * ((t * t).astype(_F) * t).astype(_F)).astype(_F)
-            mor = (mass / rj).astype(_F)
+            mor = (mass * (_F(1.0) / rj).astype(_F)).astype(_F)
             for a in range(3):
                 dv = ((vel[jj, a] - nvel[:, a]).astype(_F) * w).astype(_F)
                 xs[:, a] = np.where(acc, _fma(dv, mor, xs[:, a]), xs[:, a])

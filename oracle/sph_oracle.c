@@ -45,10 +45,11 @@
  *  8. Float -> cell index: clamp in float then convert (identical for in-range
  *     values; avoids undefined float->int overflow for far-away particles).
  *  9. Reciprocal forms.  GLSL specifies a/b only to 2.5 ULP and drivers lower it to
- *     a*rcp(b); two divisions of the force sweep are fixed in that form so they can be
- *     hoisted per neighbour / per pair: `rij / r` (SPHFluid.comp:54) is rij * (1/r) and
- *     `x / (2.0 * pj.density)` (:137) is x * (1/(2 rho_j)), each reciprocal a correctly
- *     rounded fp32 division.  Every other division is written as in the shader.
+ *     a*rcp(b).  Divisions by a NEIGHBOUR quantity are fixed in that form, with the
+ *     reciprocal a correctly rounded fp32 division, so that it can be formed once per
+ *     neighbour: invRho_j = 1/rho_j gives `mass / pj.density` (SPHFluid.comp:141,147,192)
+ *     = mass * invRho_j and `x / (2.0 * pj.density)` (:137) = (x * 0.5) * invRho_j; and
+ *     `rij / r` (:54) = rij * (1/r).  Every other division is written as in the shader.
  */
 #include <math.h>
 #include <stdint.h>
@@ -329,9 +330,9 @@ static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g
                     float invr = 1.0f / r;                   /* semantic 9: rij / r */
                     gW[0] = s * (rij[0] * invr); gW[1] = s * (rij[1] * invr); gW[2] = s * (rij[2] * invr);
                 }
-                float i2r = 1.0f / (2.0f * pj->density);     /* semantic 9: x / (2.0 * rho_j) */
-                float pterm = ((-mass) * (pi.pressure + pj->pressure)) * i2r;
-                float mor = mass / pj->density;
+                float invRho = 1.0f / pj->density;           /* semantic 9 */
+                float pterm = (((-mass) * (pi.pressure + pj->pressure)) * 0.5f) * invRho;
+                float mor = mass * invRho;
                 float lapW = k->viscC * (h - r);             /* viscLaplacian :58-64 */
                 for (int a = 0; a < 3; ++a) {
                     fP[a] = fmaf(gW[a], pterm, fP[a]);
@@ -379,7 +380,7 @@ static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g
             if (r2 < h2 && pj->density > 0.0f) {
                 float t = h2 - r2;
                 float w = k->poly6C * ((t * t) * t);
-                float mor = mass / pj->density;
+                float mor = mass * (1.0f / pj->density);     /* semantic 9 */
                 for (int a = 0; a < 3; ++a) xs[a] = fmaf((pj->vel[a] - pi.vel[a]) * w, mor, xs[a]);
                 norm = norm + w;
             }

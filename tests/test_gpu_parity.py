@@ -22,7 +22,7 @@ def make_engine(pkg, rec, sp, neighbor=0, debug=0, tile=None, aos_lazy=False):
     if debug:
         f.set_option(pkg.SPH_OPT_DEBUG, debug)
     if tile:
-        for opt, v in zip((101, 102, 103), tile):
+        for opt, v in zip((103, 102, 101), tile[::-1]):      # z, y, x: every intermediate shape fits the LDS tables
             f.set_option(opt, v)
     if aos_lazy:
         f.set_option(pkg.SPH_OPT_AOS_MODE, 1)
