@@ -23,7 +23,8 @@ struct SimK {
     float dt, maxSpeed, foamGen, foamVelRefMax;
     // grid (BuildGrid.comp:14-19)
     float gminx, gminy, gminz, cellSize;
-    int gx, gy, gz, numCells;
+    int gx, gy, gz, numCells;   // LOCAL grid (a z-slab rank: its layers plus one ghost layer each side)
+    int gzGlobal, zoff;         // global z extent and global index of local layer 0 (single GPU: gz, 0)
     // OBBConstraints.comp uniforms (:20-29)
     float R[9];
     float bcx, bcy, bcz, bhx, bhy, bhz, auxx, auxy, auxz;
@@ -35,7 +36,9 @@ struct SimK {
 enum : uint32_t {
     F_GHOST1 = 1u,    // isGhost == 1  (SPHFluid.comp:72)
     F_GHOSTNZ = 2u,   // isGhost != 0  (OBBConstraints.comp:46, WaveImpulse.comp:36)
-    F_INACTIVE = 4u   // isActive == 0 (SPHFluid.comp:73)
+    F_INACTIVE = 4u,  // isActive == 0 (SPHFluid.comp:73)
+    F_HALO = 8u,      // z-slab mode: read-only copy of a neighbour rank's boundary particle (never a target)
+    F_DEAD = 16u      // z-slab mode: slot no longer part of this rank's set (left or stale ghost); skipped by the sort
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -50,6 +53,13 @@ __device__ __forceinline__ int cell_axis(float p, float gmin, float cellSize, in
     float f = floorf(q);
     f = fminf(fmaxf(f, 0.0f), (float)(dim - 1));
     return (int)f;
+}
+
+// z cell coordinate in the LOCAL grid: the global coordinate exactly as the single-domain run
+// computes it (same clamp), shifted by the slab's first layer.
+__device__ __forceinline__ int cell_z_global(const SimK& k, float pz) { return cell_axis(pz, k.gminz, k.cellSize, k.gzGlobal); }
+__device__ __forceinline__ int cell_z_local(const SimK& k, float pz) {
+    return min(max(cell_z_global(k, pz) - k.zoff, 0), k.gz - 1);
 }
 
 // Own state of one particle while it runs through SPHFluid.comp main().

@@ -90,6 +90,11 @@ struct SphEngine {
     unsigned long long* d_stamps = nullptr;   // diagnostic tile-kernel counters (SPH_OPT_DEBUG bit 3), one row per tile
     int stampTiles = 0;
     size_t dbgCap = 0;
+    // z-slab (multi-GPU) mode: this engine owns global cell layers [z0, z1) and keeps one ghost layer per side
+    bool slab = false;
+    int z0 = 0, z1 = 0, hasLo = 0, hasHi = 0;
+    size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count
+    uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count
     // tile scheduler scratch (sph_tile.h)
     sph::TilePlan tile{};
 
@@ -147,7 +152,7 @@ void free_particle_buffers(SphEngine* e) {
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
-    dev_free(e->d_slowSlots); dev_free(e->d_slowCount);
+    dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt);
     e->cap = 0;
 }
 void free_grid_buffers(SphEngine* e) {
@@ -173,21 +178,27 @@ int alloc_particle_buffers(SphEngine* e, size_t n) {
     if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
     if ((rc = dev_alloc(&e->d_slowSlots, n))) return rc;
     if ((rc = dev_alloc(&e->d_slowCount, 4))) return rc;
+    if ((rc = dev_alloc(&e->d_slabCnt, 4))) return rc;
     e->cap = n;
     return SPH_OK;
 }
 
 // cellHead realloc of SPHFluid3D.cpp:440-447 (only when the cell count changed)
+int local_cells(const SphEngine* e) {
+    return e->slab ? e->grid.dims[0] * e->grid.dims[1] * (e->z1 - e->z0 + 2) : e->grid.numCells;
+}
+
 int ensure_grid_buffers(SphEngine* e) {
-    if (e->grid.numCells == e->allocatedCells && e->d_cellCount) return SPH_OK;
+    const int want = local_cells(e);
+    if (want == e->allocatedCells && e->d_cellCount) return SPH_OK;
     free_grid_buffers(e);
-    const size_t C = (size_t)e->grid.numCells;
+    const size_t C = (size_t)want;
     int rc;
     if ((rc = dev_alloc(&e->d_cellCount, C))) return rc;
     if ((rc = dev_alloc(&e->d_cellStart, C + 1))) return rc;
     if ((rc = dev_alloc(&e->d_blockSums, (size_t)blocks_for(C, kScanTile) + 1))) return rc;
     HIP_TRY(hipMemsetAsync(e->d_cellCount, 0, C * sizeof(uint32_t), e->stream));
-    e->allocatedCells = e->grid.numCells;
+    e->allocatedCells = want;
     return SPH_OK;
 }
 
@@ -211,6 +222,7 @@ int set_particles(SphEngine* e, const SphParticle* host, size_t n) {
 
 int import_state(SphEngine* e) {
     if (e->internalValid) return SPH_OK;
+    if (e->slab) return fail(SPH_ERR_STATE, "slab engine without a valid state");
     if (!e->aosValid) return fail(SPH_ERR_STATE, "neither the AoS nor the internal state is valid");
     if (e->n) {
         Timed t(e, SPH_K_OTHER);
@@ -226,7 +238,7 @@ int import_state(SphEngine* e) {
 // ClearGrid + BuildGrid as a counting sort: after this, d_cellStart/d_order describe the
 // current state buffer.
 int build_grid(SphEngine* e, const SimK& k) {
-    const int n = (int)e->n, C = e->grid.numCells;
+    const int n = (int)(e->slab ? e->nSlots : e->n), C = k.numCells;
     const int nb = blocks_for(n), sb = blocks_for((size_t)C, kScanTile);
     if (n) {
         Timed t(e, SPH_K_BIN);
@@ -241,13 +253,14 @@ int build_grid(SphEngine* e, const SimK& k) {
     if (n) {
         Timed t(e, SPH_K_SCATTER);
         hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n);
-        hipLaunchKernelGGL(k_rank, dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n);
+        hipLaunchKernelGGL(k_rank, dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C);
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
 }
 
 int writeback(SphEngine* e) {
+    if (e->slab) return fail(SPH_ERR_STATE, "a slab engine has no local 80-byte array: use sph_slab_download");
     if (e->aosValid) return SPH_OK;
     if (!e->internalValid) return fail(SPH_ERR_STATE, "no valid particle state");
     if (!e->accValid) return fail(SPH_ERR_STATE, "internal acc buffer is stale");
@@ -270,9 +283,13 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     if ((rc = ensure_grid_buffers(e))) return rc;                           // :440-447
     SimK k;
     make_simk(e->params, e->grid, dt, k);
+    if (e->slab) {
+        if (e->z1 > e->grid.dims[2] || e->z0 < 0) return fail(SPH_ERR_STATE, "slab [%d,%d) outside the %d-layer grid", e->z0, e->z1, e->grid.dims[2]);
+        k.gz = e->z1 - e->z0 + 2; k.numCells = k.gx * k.gy * k.gz; k.zoff = e->z0 - 1;
+    }
     if ((rc = import_state(e))) return rc;
     if ((rc = build_grid(e, k))) return rc;                                 // :449-468
-    const int n = (int)e->n;
+    const int n = (int)(e->slab ? e->nSlots : e->n);
     StateIn in{e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur]};
     const int nx = e->cur ^ 1;
     StateOut out{e->d_pos[nx], e->d_vel[nx], e->d_rp[nx], e->d_foam[nx], e->d_acc};
@@ -300,6 +317,10 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     e->cur = nx;
     e->accValid = true;
     e->aosValid = false;
+    if (e->slab) {   // the sorted output holds exactly the live particles: remember their count on the device
+        HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, e->d_cellStart + k.numCells, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+        return SPH_OK;
+    }
     if (e->optAos == 0) return writeback(e);
     return SPH_OK;
 }
@@ -493,10 +514,11 @@ int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, floa
     if (len > 1e-6f) { w.ndx = dir[0] / len; w.ndy = dir[1] / len; w.ndz = dir[2] / len; }   // WaveImpulse.comp:39
     else { w.ndx = 0.0f; w.ndy = 1.0f; w.ndz = 0.0f; }
     w.amplitude = amplitude; w.kk = 6.28318530718f / wavelength; w.phase = phase; w.yMin = yMin; w.yMax = yMax;
-    if (e->n) {
+    const size_t nw = e->slab ? e->nSlots : e->n;
+    if (nw) {
         Timed t(e, SPH_K_IMPULSE);
-        hipLaunchKernelGGL(k_wave_impulse, dim3(blocks_for(e->n)), dim3(kBlock), 0, e->stream, w, e->d_pos[e->cur], e->d_vel[e->cur],
-                           e->aosValid ? e->d_aos : nullptr, e->idBase, (int)e->n);
+        hipLaunchKernelGGL(k_wave_impulse, dim3(blocks_for(nw)), dim3(kBlock), 0, e->stream, w, e->d_pos[e->cur], e->d_vel[e->cur],
+                           (e->aosValid && !e->slab) ? e->d_aos : nullptr, e->idBase, (int)nw);
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
@@ -581,6 +603,110 @@ int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset) {
     for (int t = 0; t < e->stampTiles; ++t)
         for (int i = 0; i < count; ++i) out[i] += host[(size_t)t * sph::TS_COUNT + i];
     if (reset) HIP_TRY(hipMemset(e->d_stamps, 0, host.size() * sizeof(unsigned long long)));
+    return SPH_OK;
+}
+
+// ---- z-slab (multi-GPU) entry points -----------------------------------------------------------
+int sph_create_slab(SphEngine** out, const SphParticle* particles, const uint32_t* ids, size_t n, const SphParams* params,
+                    int z0, int z1, int hasLo, int hasHi, size_t capacity, void* stream) {
+    if ((!particles || !ids) && n) return fail(SPH_ERR_ARG, "null particles / ids");
+    if (z1 <= z0 || z0 < 0) return fail(SPH_ERR_ARG, "bad slab range [%d, %d)", z0, z1);
+    if (capacity < n) return fail(SPH_ERR_ARG, "capacity %zu < %zu particles", capacity, n);
+    SphEngine* e = nullptr;
+    int rc = create_common(out, params, stream, &e);
+    if (rc) return rc;
+    e->slab = true; e->z0 = z0; e->z1 = z1; e->hasLo = hasLo ? 1 : 0; e->hasHi = hasHi ? 1 : 0;
+    sph::compute_grid_extents(e->params, e->grid);
+    uint32_t* d_ids = nullptr;
+    auto cleanup = [&](int code) { if (d_ids) (void)hipFree(d_ids); sph_destroy(e); return code; };
+    if ((rc = alloc_particle_buffers(e, capacity))) return cleanup(rc);
+    if ((rc = ensure_grid_buffers(e))) return cleanup(rc);
+    e->n = n; e->nSlots = n;
+    if (n) {
+        if ((rc = dev_alloc(&d_ids, n))) return cleanup(rc);
+        hipError_t er = hipMemcpyAsync(e->d_aos, particles, n * sizeof(SphParticle), hipMemcpyHostToDevice, e->stream);
+        if (er == hipSuccess) er = hipMemcpyAsync(d_ids, ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+        if (er != hipSuccess) return cleanup(fail(SPH_ERR_HIP, "upload failed: %s", hipGetErrorString(er)));
+        hipLaunchKernelGGL(k_slab_import, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, e->d_aos, d_ids, e->d_pos[0], e->d_vel[0], e->d_rp[0], e->d_foam[0], (int)n);
+    }
+    const uint32_t init[4] = {0u, 0u, (uint32_t)n, 0u};
+    hipError_t er = hipMemcpyAsync(e->d_slabCnt, init, sizeof(init), hipMemcpyHostToDevice, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    if (er != hipSuccess) return cleanup(fail(SPH_ERR_HIP, "slab init failed: %s", hipGetErrorString(er)));
+    if (d_ids) (void)hipFree(d_ids);
+    e->cur = 0; e->internalValid = true; e->aosValid = false; e->accValid = false;
+    *out = e;
+    return SPH_OK;
+}
+
+int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint32_t capHi, uint32_t countsOut[2]) {
+    if (!e || !countsOut) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    if ((e->hasLo && !sendLo) || (e->hasHi && !sendHi)) return fail(SPH_ERR_ARG, "missing send buffer");
+    sph::compute_grid_extents(e->params, e->grid);
+    SimK k;
+    make_simk(e->params, e->grid, e->params.param_timeStep, k);
+    HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 2 * sizeof(uint32_t), e->stream));
+    uint32_t host[3] = {0, 0, 0};
+    // the live count of the previous dispatch bounds the slots that hold real data
+    HIP_TRY(hipMemcpyAsync(&host[2], e->d_slabCnt + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->nSlots = host[2];
+    if (e->nSlots) {
+        Timed t(e, SPH_K_OTHER);
+        hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->nSlots)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
+                           e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], (int)e->nSlots,
+                           (SlabRec*)sendLo, (SlabRec*)sendHi, capLo, capHi, e->d_slabCnt);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (host[0] > capLo || host[1] > capHi) return fail(SPH_ERR_CAPACITY, "halo send buffer too small (%u/%u lo, %u/%u hi)", host[0], capLo, host[1], capHi);
+    countsOut[0] = host[0]; countsOut[1] = host[1];
+    return SPH_OK;
+}
+
+int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* recvHi, uint32_t nHi) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    if ((nLo && !recvLo) || (nHi && !recvHi)) return fail(SPH_ERR_ARG, "missing receive buffer");
+    if (e->nSlots + nLo + nHi > e->cap) return fail(SPH_ERR_CAPACITY, "slab capacity %zu < %zu slots", e->cap, e->nSlots + nLo + nHi);
+    const int c = e->cur;
+    if (nLo) hipLaunchKernelGGL(k_slab_unpack, dim3(blocks_for(nLo)), dim3(kBlock), 0, e->stream, (const SlabRec*)recvLo, (int)nLo,
+                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], (int)e->nSlots);
+    e->nSlots += nLo;
+    if (nHi) hipLaunchKernelGGL(k_slab_unpack, dim3(blocks_for(nHi)), dim3(kBlock), 0, e->stream, (const SlabRec*)recvHi, (int)nHi,
+                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], (int)e->nSlots);
+    e->nSlots += nHi;
+    HIP_TRY(hipGetLastError());
+    const uint32_t slots = (uint32_t)e->nSlots;   // until the next dispatch sorts again, every slot may hold data
+    HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, &slots, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SPH_OK;
+}
+
+int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nOut) {
+    if (!e || !nOut || (!hostOut && capRecords)) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    uint32_t live = 0;
+    HIP_TRY(hipMemcpyAsync(&live, e->d_slabCnt + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t n = live;
+    SlabOut* d_out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&d_out, n ? n : 1))) return rc;
+    hipError_t er = hipMemsetAsync(e->d_slabCnt + 3, 0, sizeof(uint32_t), e->stream);
+    if (er == hipSuccess && n)
+        hipLaunchKernelGGL(k_slab_download, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur],
+                           e->d_foam[e->cur], e->d_acc, (int)n, e->accValid ? 1 : 0, d_out, (uint32_t)n, e->d_slabCnt + 3);
+    uint32_t cnt = 0;
+    if (er == hipSuccess) er = hipMemcpyAsync(&cnt, e->d_slabCnt + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    if (er == hipSuccess && cnt > capRecords) { (void)hipFree(d_out); return fail(SPH_ERR_CAPACITY, "%u owned records > capacity %zu", cnt, capRecords); }
+    if (er == hipSuccess && cnt) er = hipMemcpy(hostOut, d_out, (size_t)cnt * sizeof(SlabOut), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (er != hipSuccess) return fail(SPH_ERR_HIP, "slab download failed: %s", hipGetErrorString(er));
+    *nOut = cnt;
     return SPH_OK;
 }
 

@@ -114,6 +114,7 @@ inline void make_simk(const SphParams& p, const SphGridInfo& g, float dt, SimK& 
     k.gminx = g.gridMin[0]; k.gminy = g.gridMin[1]; k.gminz = g.gridMin[2];
     k.cellSize = g.cellSize;
     k.gx = g.dims[0]; k.gy = g.dims[1]; k.gz = g.dims[2]; k.numCells = g.numCells;
+    k.gzGlobal = g.dims[2]; k.zoff = 0;
     rotation_mat3(p.param_boxEulerDeg, k.R);
     k.bcx = p.param_boxCenter[0]; k.bcy = p.param_boxCenter[1]; k.bcz = p.param_boxCenter[2];
     k.bhx = p.param_boxHalf[0]; k.bhy = p.param_boxHalf[1]; k.bhz = p.param_boxHalf[2];

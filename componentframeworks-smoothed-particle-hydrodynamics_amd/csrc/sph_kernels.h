@@ -48,14 +48,14 @@ __global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict
                                                 uint32_t* __restrict__ slotOf, uint32_t* __restrict__ cellCount, int n) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool valid = i < n;
-    uint32_t cell = 0xFFFFFFFFu;
-    if (valid) {
+    const bool inRange = i < n;
+    uint32_t cell = 0xFFFFFFFFu;              // also the key of dead slots (z-slab mode): they get no slot
+    if (inRange) {
         const float4 p = pos[i];
         const int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
         const int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
-        const int cz = cell_axis(p.z, k.gminz, k.cellSize, k.gz);
-        cell = (uint32_t)((cz * k.gy + cy) * k.gx + cx);   // flatten(), BuildGrid.comp:19
+        const int cz = cell_z_local(k, p.z);
+        if (!(fbits(p.w) & F_DEAD)) cell = (uint32_t)((cz * k.gy + cy) * k.gx + cx);   // flatten(), BuildGrid.comp:19
     }
     const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
     const bool head = (lane == 0) || (cell != prev);
@@ -65,9 +65,10 @@ __global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict
     const unsigned long long above = heads & ~upto;
     const int endLane = above ? (__ffsll((long long)above) - 1) : 64;
     uint32_t base = 0;
+    const bool valid = cell != 0xFFFFFFFFu;
     if (head && valid) base = atomicAdd(&cellCount[cell], (uint32_t)(endLane - lane));
     base = (uint32_t)__shfl((int)base, startLane, 64);
-    if (valid) {
+    if (inRange) {
         cellOf[i] = cell;
         slotOf[i] = base + (uint32_t)(lane - startLane);
     }
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cn
         if (c < numCells) { cellStart[c] = carry + ex; cnt[c] = 0u; }
         carry += total;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) cellStart[numCells] = nTotal;
+    // total = live particles (in z-slab mode nTotal, the slot count, also covers dead slots)
+    (void)nTotal;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) cellStart[numCells] = carry;
 }
 
 // ---- counting-sort scatter: tmp[slot] = (particle id, source index) ---------------------
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
                                                     uint2* __restrict__ tmp, int n) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    if (cellOf[i] == 0xFFFFFFFFu) return;     // dead slot (z-slab mode)
     uint32_t dst = cellStart[cellOf[i]] + slotOf[i];
     tmp[dst] = make_uint2(fbits(vel[i].w), (uint32_t)i);
 }
@@ -161,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
 // (atomic arrival order in k_bin is arbitrary, exactly like BuildGrid.comp's atomicExchange;
 // this pass removes that freedom.)  order[s] = source index of the particle in sorted slot s.
 __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,
-                                                 const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n) {
+                                                 const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells) {
     int d = blockIdx.x * kBlock + threadIdx.x;
-    if (d >= n) return;
+    if (d >= n || (uint32_t)d >= cellStart[numCells]) return;   // live particles only (cellStart[numCells] <= n)
     uint2 me = tmp[d];
     uint32_t c = cellOf[me.y];
     uint32_t s = cellStart[c], e = cellStart[c + 1];
@@ -227,6 +231,7 @@ __device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in,
     const float2 RP = in.rp[src];
     const float foamIn = in.foam[src];
     const uint32_t flags = fbits(P.w), id = fbits(V.w);
+    if (flags & F_HALO) { out.pos[s] = P; return; }          // neighbour rank's particle: candidate only
     Own o;
     own_reset(o);
     o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = RP.x; o.prs = RP.y;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in,
     }
     const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
     const int cy = cell_axis(P.y, k.gminy, k.cellSize, k.gy);
-    const int cz = cell_axis(P.z, k.gminz, k.cellSize, k.gz);
+    const int cz = cell_z_local(k, P.z);
 
     for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
         const float4 J = in.pos[order[q]];
@@ -270,7 +275,7 @@ __device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in,
 __global__ __launch_bounds__(kBlock) void k_sph_gather(SimK k, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                        const uint32_t* __restrict__ cellStart, int n) {
     const int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= n) return;
+    if (s >= n || (uint32_t)s >= cellStart[k.numCells]) return;
     sph_gather_one(k, in, out, order, cellStart, s);
 }
 
@@ -337,8 +342,141 @@ __global__ __launch_bounds__(kBlock) void k_debug_particle_cell(SimK k, const fl
     float4 p = pos[s];
     int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
     int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
-    int cz = cell_axis(p.z, k.gminz, k.cellSize, k.gz);
+    int cz = cell_z_local(k, p.z);
     particleCell[fbits(vel[s].w) - idBase] = (cz * k.gy + cy) * k.gx + cx;
+}
+
+
+// ======================= z-slab (multi-GPU) support ==========================================
+// 48-byte record that crosses ranks: a migrant (flags without F_HALO: the receiver owns it)
+// or a boundary-layer copy (F_HALO set: candidate only).
+struct SlabRec {
+    float px, py, pz, vx, vy, vz, rho, prs, foam;
+    uint32_t id, flags, pad;
+};
+static_assert(sizeof(SlabRec) == 48, "SlabRec is 48 bytes");
+
+__global__ __launch_bounds__(kBlock) void k_slab_import(const SphParticle* __restrict__ aos, const uint32_t* __restrict__ ids,
+                                                        float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
+                                                        float* __restrict__ foam, int n) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* rec = reinterpret_cast<const float4*>(aos + i);
+    float4 p = rec[0], v = rec[1], d = rec[3];
+    int4 fl = *reinterpret_cast<const int4*>(rec + 4);
+    uint32_t flags = (fl.x == 1 ? F_GHOST1 : 0u) | (fl.x != 0 ? F_GHOSTNZ : 0u) | (fl.y == 0 ? F_INACTIVE : 0u);
+    pos[i] = make_float4(p.x, p.y, p.z, bitsf(flags));
+    vel[i] = make_float4(v.x, v.y, v.z, bitsf(ids[i]));
+    rp[i] = make_float2(d.x, d.y);
+    foam[i] = d.z;
+}
+
+__device__ __forceinline__ void slab_append(SlabRec* buf, uint32_t* counter, uint32_t cap, bool pred, const SlabRec& r) {
+    const unsigned long long m = __ballot(pred);
+    if (!pred) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot < cap) buf[slot] = r;
+}
+
+// Start of a substep on a slab rank [z0, z1): classify every local slot by its CURRENT position.
+//   stale ghost                      -> dead
+//   owned, still inside              -> stays; copied to the neighbour as a ghost if in a boundary layer
+//   owned, crossed into a neighbour  -> record sent as a migrant; kept here as a ghost if it sits in the
+//                                       adjacent layer, otherwise dead
+// counters[0] = records for the lower neighbour, counters[1] = for the upper neighbour.
+__global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, int hasLo, int hasHi, float4* __restrict__ pos,
+                                                      const float4* __restrict__ vel, const float2* __restrict__ rp,
+                                                      const float* __restrict__ foam, int n, SlabRec* __restrict__ sendLo,
+                                                      SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi,
+                                                      uint32_t* __restrict__ counters) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool toLoBuf = false, toHiBuf = false;
+    SlabRec r;
+    r.px = r.py = r.pz = r.vx = r.vy = r.vz = r.rho = r.prs = r.foam = 0.0f; r.id = 0; r.flags = 0; r.pad = 0;
+    uint32_t fLo = 0, fHi = 0;
+    if (i < n) {
+        const float4 P = pos[i];
+        uint32_t flags = fbits(P.w);
+        if (!(flags & F_DEAD)) {
+            if (flags & F_HALO) {
+                pos[i].w = bitsf(flags | F_DEAD);
+            } else {
+                const int cz = cell_z_global(k, P.z);
+                const bool goLo = cz < z0, goHi = cz >= z1;
+                const float4 V = vel[i];
+                const float2 RP = rp[i];
+                r.px = P.x; r.py = P.y; r.pz = P.z; r.vx = V.x; r.vy = V.y; r.vz = V.z;
+                r.rho = RP.x; r.prs = RP.y; r.foam = foam[i]; r.id = fbits(V.w);
+                toLoBuf = hasLo && (goLo || cz == z0);
+                toHiBuf = hasHi && (goHi || cz == z1 - 1);
+                fLo = goLo ? flags : (flags | F_HALO);
+                fHi = goHi ? flags : (flags | F_HALO);
+                if (goLo) pos[i].w = bitsf(cz == z0 - 1 ? (flags | F_HALO) : (flags | F_DEAD));
+                if (goHi) pos[i].w = bitsf(cz == z1 ? (flags | F_HALO) : (flags | F_DEAD));
+            }
+        }
+    }
+    r.flags = fLo;
+    slab_append(sendLo, &counters[0], capLo, toLoBuf, r);
+    r.flags = fHi;
+    slab_append(sendHi, &counters[1], capHi, toHiBuf, r);
+}
+
+// Append received records behind the local slots.
+__global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restrict__ recv, int nRecv, float4* __restrict__ pos,
+                                                        float4* __restrict__ vel, float2* __restrict__ rp, float* __restrict__ foam,
+                                                        int dstBase) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nRecv) return;
+    const SlabRec r = recv[i];
+    const int d = dstBase + i;
+    pos[d] = make_float4(r.px, r.py, r.pz, bitsf(r.flags));
+    vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
+    rp[d] = make_float2(r.rho, r.prs);
+    foam[d] = r.foam;
+}
+
+// Owned particles of a slab rank as 64-byte records (pos3, vel3, acc3, rho, P, foam, id, flags, 2 pad),
+// compacted; *count receives the number written.
+struct SlabOut {
+    float px, py, pz, vx, vy, vz, ax, ay, az, rho, prs, foam;
+    uint32_t id, flags, pad0, pad1;
+};
+static_assert(sizeof(SlabOut) == 64, "SlabOut is 64 bytes");
+__global__ __launch_bounds__(kBlock) void k_slab_download(const float4* __restrict__ pos, const float4* __restrict__ vel,
+                                                          const float2* __restrict__ rp, const float* __restrict__ foam,
+                                                          const float4* __restrict__ acc, int n, int accValid, SlabOut* __restrict__ out,
+                                                          uint32_t cap, uint32_t* __restrict__ count) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool own = false;
+    SlabOut o;
+    o.px = o.py = o.pz = o.vx = o.vy = o.vz = o.ax = o.ay = o.az = o.rho = o.prs = o.foam = 0.0f; o.id = o.flags = o.pad0 = o.pad1 = 0;
+    if (i < n) {
+        const float4 P = pos[i];
+        const uint32_t flags = fbits(P.w);
+        if (!(flags & (F_DEAD | F_HALO))) {
+            own = true;
+            const float4 V = vel[i];
+            const float2 RP = rp[i];
+            o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z;
+            if (accValid) { const float4 A = acc[i]; o.ax = A.x; o.ay = A.y; o.az = A.z; }
+            o.rho = RP.x; o.prs = RP.y; o.foam = foam[i]; o.id = fbits(V.w); o.flags = flags;
+        }
+    }
+    const unsigned long long m = __ballot(own);
+    if (!own) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot < cap) out[slot] = o;
 }
 
 }  // namespace sph

@@ -392,6 +392,10 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         if (STAMP && wlead) { stamp_add<STAMP>(st, TS_SCAN, w1 - w0); stamp_add<STAMP>(st, TS_WAVEROUNDS, 1); stamp_add<STAMP>(st, TS_SCANGROUPS, groups); }
 
         const uint32_t flags = fbits(P.w), id = fbits(V.w);
+        if (flags & F_HALO) {                                      // neighbour rank's particle: candidate only
+            if (valid) out.pos[s] = P;
+            continue;
+        }
         if (flags & F_GHOST1) {                                    // SPHFluid.comp:72-83
             if (valid) {
                 float gvx = V.x, gvy = V.y, gvz = V.z, grho = in.rp[src].x, gprs = LV.w;

@@ -69,7 +69,7 @@ ABI_SYMBOLS = (
     "sph_set_option", "sph_get_option", "sph_dispatch", "sph_dispatch_n", "sph_apply_wave_impulse",
     "sph_num_particles", "sph_grid_info", "sph_upload_particles", "sph_download_particles",
     "sph_device_particles", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
-    "sph_debug_counters",
+    "sph_debug_counters", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
 )
 STAMP_NAMES = ("prologue", "stage", "lists", "scan", "sweep2", "sweep3", "epilogue", "total", "tiles", "slices", "waverounds",
                "scangroups", "overflow_slices", "slow_lanes", "targets", "candidates", "walk2max", "walk2sum", "rescan_lanes")
@@ -95,6 +95,15 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
         _build.build()
     if not os.path.exists(_build.LIB_PATH):
         raise SphError(f"{_build.LIB_PATH} is missing: run __graft_entry__.build(); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname as the
+    # system one).  Whichever loads first wins, and torch cannot see the GPU behind the system
+    # runtime, so let torch load first when it is installed (it is only plumbing here: halo
+    # buffers, streams, torch.distributed).
+    if os.environ.get("SPH_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(_build.LIB_PATH)
     vp, pp, gp = C.c_void_p, C.POINTER(SphParams), C.POINTER(SphGridInfo)
     f3 = C.POINTER(C.c_float)
@@ -127,6 +136,10 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_sync.argtypes = [vp]
     L.sph_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.sph_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_int]
+    L.sph_create_slab.argtypes = [C.POINTER(vp), vp, vp, C.c_size_t, pp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp]
+    L.sph_slab_pack.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.sph_slab_unpack.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    L.sph_slab_download.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version"):

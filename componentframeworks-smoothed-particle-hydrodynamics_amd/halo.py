@@ -1,0 +1,298 @@
+"""z-slab domain decomposition with a one-deep halo exchange.
+
+The reference is single-GPU; this module is new functionality.  Rank r owns the global cell
+layers [z0_r, z1_r) of the grid ComputeGridExtents defines (z is the slowest index of the
+reference's cell = (cz*gy + cy)*gx + cx, so a slab is a contiguous cell range).  The
+interaction radius equals the cell size, and the SPH pass reads only the dispatch-entry
+snapshot of its neighbours, so ONE exchange per substep suffices:
+
+    pack      every rank classifies its particles by current position and emits, per z-neighbour,
+              one stream of 48-byte records: migrants (now owned by the neighbour) and copies of
+              its boundary-layer particles (ghosts for the neighbour)
+    exchange  counts, then payload, with at most two neighbours (torch.distributed send/recv:
+              RCCL over xGMI with backend "nccl"; "gloo" + host staging for CPU rehearsals)
+    unpack    received records are appended to the local state
+    dispatch  the ordinary substep; ghosts are neighbour candidates, never targets
+
+Summation order is (cell index, GLOBAL particle id), so every rank computes bit for bit what a
+single-domain run computes: tests/test_halo_cpu.py (gloo, oracle stand-in engine) and
+tests/test_gpu_slab.py (HIP engines) check exactly that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import engine as _eng
+from . import synthetic as _syn
+
+REC_WORDS = 12          # 48-byte exchange record
+OUT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("vel", "<f4", (3,)), ("acc", "<f4", (3,)), ("density", "<f4"),
+                      ("pressure", "<f4"), ("padA", "<f4"), ("id", "<u4"), ("flags", "<u4"), ("pad", "<u4", (2,))])
+assert OUT_DTYPE.itemsize == 64
+
+
+def slab_range(gz: int, rank: int, world: int):
+    """Even split of gz cell layers; every rank gets at least one layer."""
+    if world > gz:
+        raise ValueError(f"{world} ranks for {gz} cell layers")
+    return (gz * rank) // world, (gz * (rank + 1)) // world
+
+
+class HipSlabEngine:
+    """One rank's engine in slab mode (sph_create_slab / sph_slab_* of include/sph_abi.h)."""
+
+    def __init__(self, particles, ids, params, z0, z1, has_lo, has_hi, capacity, stream=None):
+        self._L = _eng.load_library()
+        self._h = C.c_void_p()
+        self._p = params
+        rec = np.ascontiguousarray(particles, dtype=_eng.PARTICLE_DTYPE)
+        idv = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert len(rec) == len(idv)
+        _eng._check(self._L.sph_create_slab(C.byref(self._h), rec.ctypes.data_as(C.c_void_p), idv.ctypes.data_as(C.c_void_p), len(rec),
+                                            C.byref(params), z0, z1, int(has_lo), int(has_hi), int(capacity), stream))
+        self.capacity = int(capacity)
+
+    device = "cuda"
+
+    def pack(self, send_lo, send_hi):
+        counts = (C.c_uint32 * 2)()
+        plo = send_lo.data_ptr() if send_lo is not None else None
+        phi = send_hi.data_ptr() if send_hi is not None else None
+        clo = send_lo.shape[0] if send_lo is not None else 0
+        chi = send_hi.shape[0] if send_hi is not None else 0
+        _eng._check(self._L.sph_slab_pack(self._h, plo, phi, clo, chi, counts))
+        return int(counts[0]), int(counts[1])
+
+    def unpack(self, recv_lo, n_lo, recv_hi, n_hi):
+        plo = recv_lo.data_ptr() if (recv_lo is not None and n_lo) else None
+        phi = recv_hi.data_ptr() if (recv_hi is not None and n_hi) else None
+        _eng._check(self._L.sph_slab_unpack(self._h, plo, n_lo, phi, n_hi))
+
+    def dispatch(self, dt=-1.0):
+        _eng._check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        _eng._check(self._L.sph_dispatch(self._h, dt))
+
+    def apply_wave_impulse(self, amplitude, wavelength, phase, direction, y_min, y_max):
+        _eng._check(self._L.sph_apply_wave_impulse(self._h, amplitude, wavelength, phase, _eng._f3(direction), y_min, y_max))
+
+    def set_option(self, option, value):
+        _eng._check(self._L.sph_set_option(self._h, option, value))
+
+    def kernel_times(self, reset=False):
+        ms = (C.c_double * len(_eng.KERNEL_CLASSES))()
+        cnt = (C.c_int64 * len(_eng.KERNEL_CLASSES))()
+        _eng._check(self._L.sph_kernel_times(self._h, ms, cnt, 1 if reset else 0))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(_eng.KERNEL_CLASSES)}
+
+    def download_owned(self) -> np.ndarray:
+        out = np.zeros(self.capacity, OUT_DTYPE)
+        n = C.c_size_t()
+        _eng._check(self._L.sph_slab_download(self._h, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def close(self):
+        if self._h:
+            self._L.sph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HaloExchange:
+    """Counts + payload exchange with the (at most two) z-neighbours over torch.distributed.
+
+    transport "direct": tensors are sent as they are (device tensors with backend nccl = RCCL).
+    transport "host":   device tensors are staged through host memory (backend gloo)."""
+
+    def __init__(self, rank, world, group=None, transport="direct", device="cpu"):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        self.transport = transport
+        self.device = device
+        self.lo = rank - 1 if rank > 0 else None
+        self.hi = rank + 1 if rank < world - 1 else None
+        cdev = device if transport == "direct" else "cpu"
+        self._cnt_send = torch.zeros(2, dtype=torch.int64, device=cdev)
+        self._cnt_recv = torch.zeros(2, dtype=torch.int64, device=cdev)
+
+    def _batch(self, ops):
+        dist = self.torch.distributed
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def exchange(self, send_lo, n_lo, send_hi, n_hi, recv_lo, recv_hi):
+        """Returns (m_lo, m_hi): records received from the lower / upper neighbour, written to the
+        head of recv_lo / recv_hi."""
+        torch, dist = self.torch, self.torch.distributed
+        self._cnt_send[0] = n_lo
+        self._cnt_send[1] = n_hi
+        self._cnt_recv.zero_()
+        ops = []
+        if self.lo is not None:
+            ops.append(dist.P2POp(dist.isend, self._cnt_send[0:1], self.lo, self.group))
+            ops.append(dist.P2POp(dist.irecv, self._cnt_recv[0:1], self.lo, self.group))
+        if self.hi is not None:
+            ops.append(dist.P2POp(dist.isend, self._cnt_send[1:2], self.hi, self.group))
+            ops.append(dist.P2POp(dist.irecv, self._cnt_recv[1:2], self.hi, self.group))
+        self._batch(ops)
+        m_lo, m_hi = (int(x) for x in self._cnt_recv.tolist())
+        if (recv_lo is not None and m_lo > recv_lo.shape[0]) or (recv_hi is not None and m_hi > recv_hi.shape[0]):
+            raise _eng.SphError(f"halo receive buffer too small ({m_lo}, {m_hi})")
+        host = self.transport == "host"
+        stage = []
+        ops = []
+
+        def snd(buf, n, peer):
+            if peer is not None and n:
+                t = buf[:n].cpu() if host else buf[:n]
+                ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+
+        def rcv(buf, n, peer):
+            if peer is not None and n:
+                t = torch.empty((n, buf.shape[1]), dtype=buf.dtype) if host else buf[:n]
+                if host:
+                    stage.append((buf, n, t))
+                ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+
+        snd(send_lo, n_lo, self.lo)
+        rcv(recv_lo, m_lo, self.lo)
+        snd(send_hi, n_hi, self.hi)
+        rcv(recv_hi, m_hi, self.hi)
+        self._batch(ops)
+        for buf, n, t in stage:
+            buf[:n].copy_(t)
+        return m_lo, m_hi
+
+
+class SlabSimulation:
+    """One rank of the decomposed simulation, with the reference's method names where they apply."""
+
+    def __init__(self, engine, exchange, rank, world, z_range, grid_dims, face_capacity, make_buffer):
+        self.engine, self.exchange = engine, exchange
+        self.rank, self.world = rank, world
+        self.z0, self.z1 = z_range
+        self.grid_dims = tuple(grid_dims)
+        self.has_lo, self.has_hi = rank > 0, rank < world - 1
+        self.send_lo = make_buffer(face_capacity) if self.has_lo else None
+        self.recv_lo = make_buffer(face_capacity) if self.has_lo else None
+        self.send_hi = make_buffer(face_capacity) if self.has_hi else None
+        self.recv_hi = make_buffer(face_capacity) if self.has_hi else None
+        self.last_counts = (0, 0, 0, 0)
+        self._n_owned0 = None
+
+    # -- construction from a synthetic config (bench.py) ---------------------------------------
+    @classmethod
+    def from_config(cls, cfg, params, rank, world, stream=None, group=None, transport="direct"):
+        import torch
+        gx, gy, gz = cfg.grid
+        z0, z1 = slab_range(gz, rank, world)
+        rec, gid = _syn.make_particles(cfg, z_cells=(z0, z1))
+        per_layer = max(1, len(rec) // max(1, z1 - z0))
+        face_cap = int(per_layer * 4 + 4096)
+        cap = int(len(rec) * 1.3 + 4 * face_cap)
+        eng = HipSlabEngine(rec, gid.astype(np.uint32), params, z0, z1, rank > 0, rank < world - 1, cap, stream=stream)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ex = HaloExchange(rank, world, group=group, transport=transport, device=dev)
+        sim = cls(eng, ex, rank, world, (z0, z1), cfg.grid, face_cap,
+                  lambda n: torch.zeros((n, REC_WORDS), dtype=torch.float32, device=dev))
+        sim._n_owned0 = len(rec)
+        return sim
+
+    # -- the substep -------------------------------------------------------------------------------
+    def DispatchCompute(self, overrideDt: float = -1.0):
+        n_lo, n_hi = self.engine.pack(self.send_lo, self.send_hi)
+        m_lo, m_hi = self.exchange.exchange(self.send_lo, n_lo, self.send_hi, n_hi, self.recv_lo, self.recv_hi)
+        self.engine.unpack(self.recv_lo, m_lo, self.recv_hi, m_hi)
+        self.engine.dispatch(overrideDt)
+        self.last_counts = (n_lo, n_hi, m_lo, m_hi)
+
+    SimulateSubstep = DispatchCompute
+
+    def ApplyWaveImpulse(self, amplitude, wavelength, phase, dir, yMin=-_eng.FLT_MAX, yMax=_eng.FLT_MAX):
+        self.engine.apply_wave_impulse(amplitude, wavelength, phase, dir, yMin, yMax)
+
+    # -- helpers used by bench.py / tests --------------------------------------------------------
+    def set_option(self, option, value):
+        self.engine.set_option(option, value)
+
+    def kernel_times(self, reset=False):
+        return self.engine.kernel_times(reset)
+
+    def num_owned(self) -> int:
+        return self._n_owned0 if self._n_owned0 is not None else len(self.engine.download_owned())
+
+    def local_grid(self) -> dict:
+        gx, gy, _ = self.grid_dims
+        return {"dims": (gx, gy, self.z1 - self.z0 + 2), "numCells": gx * gy * (self.z1 - self.z0 + 2)}
+
+    def download_owned(self) -> np.ndarray:
+        return self.engine.download_owned()
+
+
+class SlabGroup:
+    """W slab ranks inside one process, exchanging through direct buffer hand-off (no
+    torch.distributed).  Used to validate the HIP pack/unpack/ghost path on a single GPU and as
+    the reference driver for the CPU stand-in engine."""
+
+    def __init__(self, sims):
+        self.sims = sims
+
+    @classmethod
+    def from_particles(cls, particles, ids, params, grid_dims, world, make_engine, make_buffer, face_capacity, cell_z):
+        """cell_z: global z cell of every particle (decides the initial owner)."""
+        sims = []
+        gz = grid_dims[2]
+        for r in range(world):
+            z0, z1 = slab_range(gz, r, world)
+            m = (cell_z >= z0) & (cell_z < z1)
+            eng = make_engine(particles[m], ids[m], params, z0, z1, r > 0, r < world - 1)
+            sims.append(SlabSimulation(eng, None, r, world, (z0, z1), grid_dims, face_capacity, make_buffer))
+        return cls(sims)
+
+    def DispatchCompute(self, overrideDt: float = -1.0):
+        counts = [s.engine.pack(s.send_lo, s.send_hi) for s in self.sims]
+        for r, s in enumerate(self.sims):
+            lo_buf, m_lo, hi_buf, m_hi = None, 0, None, 0
+            if r > 0:
+                lo_buf, m_lo = self.sims[r - 1].send_hi, counts[r - 1][1]
+            if r < len(self.sims) - 1:
+                hi_buf, m_hi = self.sims[r + 1].send_lo, counts[r + 1][0]
+            s.engine.unpack(lo_buf, m_lo, hi_buf, m_hi)
+            s.last_counts = (counts[r][0], counts[r][1], m_lo, m_hi)
+        for s in self.sims:
+            s.engine.dispatch(overrideDt)
+
+    def ApplyWaveImpulse(self, *a, **kw):
+        for s in self.sims:
+            s.ApplyWaveImpulse(*a, **kw)
+
+    def download(self) -> np.ndarray:
+        """All owned records of all ranks, sorted by global id."""
+        parts = [s.download_owned() for s in self.sims]
+        out = np.concatenate(parts) if parts else np.zeros(0, OUT_DTYPE)
+        return out[np.argsort(out["id"], kind="stable")]
+
+
+def merge_into_records(initial: np.ndarray, owned: np.ndarray) -> np.ndarray:
+    """Global 80-byte array in ORIGINAL order from the ranks' owned records: dynamic fields come
+    from the owned records (by global id = original index), constant fields from `initial`."""
+    out = initial.copy()
+    idx = owned["id"].astype(np.int64)
+    fluid = (initial["isGhost"][idx] != 1)
+    i_f = idx[fluid]
+    out["pos"][i_f, :3] = owned["pos"][fluid]
+    out["vel"][i_f, :3] = owned["vel"][fluid]
+    out["acc"][i_f, :3] = owned["acc"][fluid]
+    out["acc"][i_f, 3] = 0.0
+    out["density"][i_f] = owned["density"][fluid]
+    out["pressure"][i_f] = owned["pressure"][fluid]
+    out["padA"][i_f] = owned["padA"][fluid]
+    return out

@@ -181,6 +181,25 @@ int sph_sync(SphEngine* e);
  * tile statistics, in the order of enum TileStamp in csrc/sph_tile.h.  Never used on a timed path. */
 int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset);
 
+/* ---- multi-GPU: z-slab decomposition (no reference counterpart) ------------
+ * One engine per rank owns the global cell layers [z0, z1) of ComputeGridExtents' grid plus one
+ * read-only ghost layer per side.  Per substep the host calls pack -> (exchange) -> unpack ->
+ * sph_dispatch.  Records crossing ranks are 48 bytes: float px,py,pz,vx,vy,vz,rho,prs,foam;
+ * uint32 id, flags, pad.  Buffers passed to pack/unpack are DEVICE pointers. */
+#define SPH_SLAB_REC_BYTES 48
+#define SPH_SLAB_OUT_BYTES 64
+/* `ids` are global particle ids (they fix the summation order, so results do not depend on the
+ * decomposition); `capacity` bounds owned + ghost + migrated-in slots. */
+int sph_create_slab(SphEngine** out, const SphParticle* particles, const uint32_t* ids, size_t n,
+                    const SphParams* params, int z0, int z1, int hasLo, int hasHi, size_t capacity, void* stream);
+/* Classify by current position, emit records for the lower / upper neighbour (migrants + boundary
+ * layer copies); countsOut = records written per direction.  Synchronises. */
+int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint32_t capHi, uint32_t countsOut[2]);
+/* Append the records received from the lower / upper neighbour. */
+int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* recvHi, uint32_t nHi);
+/* Owned particles as 64-byte records (pos3, vel3, acc3, rho, P, foam, uint32 id, flags, 2 pad) into host memory. */
+int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nOut);
+
 /* ---- measurement ----------------------------------------------------------------- */
 enum {
     SPH_K_BIN = 0,      /* cell index + histogram   (BuildGrid.comp)            */

@@ -1,0 +1,137 @@
+"""z-slab decomposition on the GPU: HIP slab engines (pack / unpack / ghost handling kernels)
+must reproduce the single-engine result BIT FOR BIT, for any number of slabs."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG_NAME, ROOT, assert_records_equal, small_scene, to_oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pkg, oracle, n=6000, grid=20, seed=51):
+    rec, sp = small_scene(pkg, n=n, grid=grid, seed=seed)
+    op = to_oracle_params(oracle, sp)
+    P = oracle.substep(rec, op, steps=2)
+    rng = np.random.default_rng(5)
+    P["vel"][:, 2] += rng.normal(0, 60, len(P)).astype(np.float32)
+    P["vel"][:, 0] += rng.normal(0, 10, len(P)).astype(np.float32)
+    return P, sp, op
+
+
+def _cell_z(pkg, sp, P):
+    g = pkg.compute_grid_extents(sp)
+    q = ((P["pos"][:, 2] - np.float32(g.gridMin[2])) / np.float32(g.cellSize)).astype(np.float32)
+    return np.clip(np.floor(q), 0, g.dims[2] - 1).astype(np.int64), tuple(g.dims)
+
+
+def _group(pkg, halo, P, sp, world, neighbor=0):
+    import torch
+    cz, dims = _cell_z(pkg, sp, P)
+    ids = np.arange(len(P), dtype=np.uint32)
+
+    def make_engine(p, i, prm, z0, z1, lo, hi):
+        e = halo.HipSlabEngine(p, i, prm, z0, z1, lo, hi, capacity=int(len(p) * 1.5) + 8192)
+        e.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)
+        return e
+
+    return halo.SlabGroup.from_particles(P, ids, sp, dims, world, make_engine,
+                                         lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), 8192, cz)
+
+
+@pytest.mark.parametrize("neighbor", [0, 1])
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_slabs_match_single_engine_and_oracle(pkg, oracle, world, neighbor):
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, world, neighbor)
+    single = pkg.SPHFluidGPU.from_particles(P, sp)
+    want = P
+    steps = 8
+    for s in range(steps):
+        if s % 3 == 0:
+            args = (1.5, 3.0, 0.1 * s, (0.2, 1.0, 0.4), -2.0, 2.0)
+            grp.ApplyWaveImpulse(*args)
+            single.ApplyWaveImpulse(*args)
+            want = oracle.wave_impulse(want, *args)
+        grp.DispatchCompute()
+        single.DispatchCompute()
+        want = oracle.substep(want, op)
+    got = halo.merge_into_records(P, grp.download())
+    assert_records_equal(got, single.download(), f"{world} slabs vs one engine")
+    assert_records_equal(got, want, f"{world} slabs vs oracle")
+    if world > 1:
+        assert sum(s.last_counts[0] + s.last_counts[1] for s in grp.sims) > 0
+    single.close()
+
+
+def test_slabs_config2_262k(pkg):
+    """BASELINE.json configs[1] size (262 144 particles, 64^3): 4 slabs == 1 engine after 5 substeps."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    syn = pkg.synthetic
+    cfg = syn.CONFIGS[2]
+    rec, _ = syn.make_particles(cfg)
+    sp = pkg.default_params(**syn.params_fields(cfg))
+    grp = _group(pkg, halo, rec, sp, 4)
+    single = pkg.SPHFluidGPU.from_particles(rec, sp)
+    for _ in range(5):
+        grp.DispatchCompute()
+        single.DispatchCompute()
+    assert_records_equal(halo.merge_into_records(rec, grp.download()), single.download(), "4 slabs at 262k")
+    # the slab generator of synthetic.py gives each rank exactly its particles
+    owned0 = grp.sims[1].download_owned()
+    z0, z1 = halo.slab_range(cfg.grid[2], 1, 4)
+    part, gid = syn.make_particles(cfg, z_cells=(z0, z1))
+    assert len(part) > 0 and set(gid.tolist()) <= set(range(cfg.n)) and len(owned0) > 0
+    single.close()
+
+
+def _gloo_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    pkg = importlib.import_module(PKG_NAME)
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, sp, op = _scene(pkg, oracle, n=4000, grid=16, seed=52)
+        cz, dims = _cell_z(pkg, sp, P)
+        z0, z1 = halo.slab_range(dims[2], rank, world)
+        m = (cz >= z0) & (cz < z1)
+        ids = np.arange(len(P), dtype=np.uint32)
+        eng = halo.HipSlabEngine(P[m], ids[m], sp, z0, z1, rank > 0, rank < world - 1, capacity=int(m.sum() * 1.5) + 8192)
+        ex = halo.HaloExchange(rank, world, transport="host", device="cuda")
+        sim = halo.SlabSimulation(eng, ex, rank, world, (z0, z1), dims, 8192,
+                                  lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"))
+        for _ in range(6):
+            sim.DispatchCompute()
+        owned = sim.download_owned()
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(owned, gathered, dst=0)
+        if rank == 0:
+            got = halo.merge_into_records(P, np.concatenate(gathered))
+            want = oracle.substep(P, op, steps=6)
+            np.save(out_path, np.array([int(got.tobytes() == want.tobytes())]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_gloo_host_staging(tmp_path):
+    """Two real ranks (two processes sharing the one GPU), torch.distributed gloo with host staging:
+    the same SlabSimulation / HaloExchange code bench.py runs with nccl."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_gloo_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1
