@@ -1,0 +1,213 @@
+// SPHFluidGPU_hip.hpp -- header-only C++17 twin of the reference class `SPHFluidGPU`
+// (/root/reference/ComponentFramework/SPHFluid3D.h:26-210) on top of the C-ABI in sph_abi.h.
+//
+// Scene0p-style code compiles against this header unchanged for the hot path: same class
+// name, same public member names (`param_*`, `numParticles`, `particles`, `gridSizeX/Y/Z`,
+// `numCells`, `gridMinV`, `cellSize`, `box`), same method names and argument meaning
+// (`DispatchCompute`, `ResetSimulation`, `ApplyWaveImpulse`, `EffectiveHalf`,
+// `ComputeGridExtents`, `GetNumFluids`).  GL object ids (`ssbo`, `fluidVBO`, ...) have no
+// counterpart; renderers take the device pointer from DeviceParticles() instead
+// (INTEGRATION.md).  Error convention as the reference: methods return void and log
+// (Debug::FatalError only logs, Debug.cpp:54); LastError() exposes the message.
+//
+// If the host project has MATH::Vec3 / Vec4 (its "MathLibrary"), define
+// SPH_HIP_HAVE_MATHLIB before including this header; otherwise minimal PODs are provided.
+#pragma once
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "sph_abi.h"
+
+#ifndef SPH_HIP_HAVE_MATHLIB
+namespace MATH {
+struct Vec3 {
+    float x = 0, y = 0, z = 0;
+    Vec3() = default;
+    Vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+};
+struct Vec4 {
+    float x = 0, y = 0, z = 0, w = 0;
+    Vec4() = default;
+    Vec4(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+};
+}  // namespace MATH
+#endif
+
+struct SPHParticle {              // SPHFluid3D.h:12-24, layout-identical to SphParticle
+    MATH::Vec4 pos, vel, acc;
+    float density, pressure, padA, padB;
+    int isGhost, isActive, padC, pad0;
+};
+static_assert(sizeof(SPHParticle) == sizeof(SphParticle), "SPHParticle must stay 80 bytes");
+
+class SPHFluidGPU {
+public:
+    explicit SPHFluidGPU(size_t numParticles_, uint32_t seed_ = 1, void* hipStream = nullptr)
+        : numParticles(numParticles_), seed(seed_), stream(hipStream) {
+        SphParams p;
+        sph_params_default(&p);
+        FromParams(p);
+        Create();
+    }
+    ~SPHFluidGPU() { sph_destroy(engine); }
+    SPHFluidGPU(const SPHFluidGPU&) = delete;
+    SPHFluidGPU& operator=(const SPHFluidGPU&) = delete;
+
+    // ---- methods Scene0p calls (Scene0p.cpp:83,1488,3739,1457,3623,1094,1467,2575,655) ----
+    void DispatchCompute(float overrideDt = -1.0f) {                    // SPHFluid3D.cpp:431
+        SphParams p = ToParams();                                       // members are re-read every dispatch (:458-506)
+        if (Check(sph_set_params(engine, &p), "sph_set_params")) return;
+        if (Check(sph_dispatch(engine, overrideDt), "sph_dispatch")) return;
+        RefreshGrid();
+    }
+    void SimulateSubstep(float overrideDt = -1.0f) { DispatchCompute(overrideDt); }   // BASELINE.json's name
+    void ResetSimulation() {                                            // SPHFluid3D.cpp:713
+        SphParams p = ToParams();
+        if (Check(sph_set_params(engine, &p), "sph_set_params")) return;
+        if (Check(sph_reset(engine, numParticles, seed), "sph_reset")) return;
+        AfterSpawn();
+        std::printf("Reset: particles=%zu fluids=%zu grid=%dx%dx%d cells=%d\n", particles.size(), numFluids, gridSizeX, gridSizeY, gridSizeZ, numCells);
+    }
+    void ApplyWaveImpulse(float amplitude, float wavelength, float phase, const MATH::Vec3& dir,
+                          float yMin = -FLT_MAX, float yMax = FLT_MAX) {   // SPHFluid3D.cpp:604
+        const float d[3] = {dir.x, dir.y, dir.z};
+        Check(sph_apply_wave_impulse(engine, amplitude, wavelength, phase, d, yMin, yMax), "sph_apply_wave_impulse");
+    }
+    MATH::Vec3 EffectiveHalf() const {                                  // SPHFluid3D.h:127
+        SphParams p = ToParams();
+        float h[3];
+        sph_effective_half(&p, h);
+        return MATH::Vec3(h[0], h[1], h[2]);
+    }
+    void ComputeGridExtents() {                                         // SPHFluid3D.cpp:354
+        SphParams p = ToParams();
+        SphGridInfo g;
+        sph_compute_grid_extents(&p, &g);
+        SetGrid(g);
+    }
+    size_t GetNumFluids() const { return numFluids; }                   // SPHFluid3D.cpp:601
+
+    // ---- what replaces the GL buffer ids -------------------------------------------------
+    const SPHParticle* DeviceParticles() {     // device pointer of the 80-byte array in original order (the `ssbo`)
+        const SphParticle* p = nullptr;
+        Check(sph_device_particles(engine, &p), "sph_device_particles");
+        return reinterpret_cast<const SPHParticle*>(p);
+    }
+    bool Download(std::vector<SPHParticle>& out) {
+        out.resize(sph_num_particles(engine));
+        return !Check(sph_download_particles(engine, reinterpret_cast<SphParticle*>(out.data()), out.size()), "sph_download_particles");
+    }
+    void Sync() { Check(sph_sync(engine), "sph_sync"); }
+    const std::string& LastError() const { return lastError; }
+    SphEngine* Handle() { return engine; }
+
+    // ---- public data members, names and defaults of SPHFluid3D.h:62-124 ------------------
+    float box = 7.0f;
+    float cellSize = 0.0f;
+    int gridSizeX = 1, gridSizeY = 1, gridSizeZ = 1;
+    int numCells = 1;
+    MATH::Vec3 gridMinV = MATH::Vec3(-7, -7, -7);
+    std::vector<SPHParticle> particles;        // initial state only, never refreshed (as in the reference)
+    size_t numParticles;
+    size_t numFluids = 0;
+
+    float param_h = 0.28f;
+    float param_mass = 13.8f;
+    float param_restDensity = 1000.0f;
+    float param_gasConstant = 2000.0f;
+    float param_viscosity = 3.5f;
+    float param_gravityY = -980.0f;
+    float param_gravityX = 0.0f;
+    float param_gravityZ = 0.0f;
+    float param_surfaceTension = 0.0728f;
+    float param_timeStep = 0.001f;
+    bool param_pause = false;
+    bool param_useJitter = true;
+    float param_jitterAmp = 0.20f;
+    float param_foamGen = 1.0f;
+    float param_foamVelRef = 8.0f;
+    MATH::Vec3 param_boxCenter = MATH::Vec3(0, 0, 0);
+    MATH::Vec3 param_boxHalf = MATH::Vec3(7, 7, 7);
+    MATH::Vec3 param_boxEulerDeg = MATH::Vec3(0, 0, 0);
+    int param_shapeType = 0;
+    MATH::Vec3 param_shapeAux = MATH::Vec3(5.0f, 0.35f, 2.5f);
+    int param_mixPattern = 0;
+    int param_dyePattern = 0;
+    float param_wallRestitution = 0.15f;
+    float param_wallFriction = 0.02f;
+    int grid_cap = 160;                        // engine extension (SPHFluid3D.cpp:370 hard-codes 160)
+    uint32_t seed;                             // engine extension (the reference seeds from time(nullptr), :99)
+
+private:
+    SphEngine* engine = nullptr;
+    void* stream = nullptr;
+    std::string lastError;
+
+    SphParams ToParams() const {
+        SphParams p;
+        sph_params_default(&p);
+        p.param_h = param_h; p.param_mass = param_mass; p.param_restDensity = param_restDensity;
+        p.param_gasConstant = param_gasConstant; p.param_viscosity = param_viscosity;
+        p.param_gravityY = param_gravityY; p.param_gravityX = param_gravityX; p.param_gravityZ = param_gravityZ;
+        p.param_surfaceTension = param_surfaceTension; p.param_timeStep = param_timeStep;
+        p.param_pause = param_pause ? 1 : 0; p.param_useJitter = param_useJitter ? 1 : 0; p.param_jitterAmp = param_jitterAmp;
+        p.param_foamGen = param_foamGen; p.param_foamVelRef = param_foamVelRef;
+        const MATH::Vec3* v[4] = {&param_boxCenter, &param_boxHalf, &param_boxEulerDeg, &param_shapeAux};
+        float* d[4] = {p.param_boxCenter, p.param_boxHalf, p.param_boxEulerDeg, p.param_shapeAux};
+        for (int i = 0; i < 4; ++i) { d[i][0] = v[i]->x; d[i][1] = v[i]->y; d[i][2] = v[i]->z; }
+        p.param_shapeType = param_shapeType; p.param_mixPattern = param_mixPattern; p.param_dyePattern = param_dyePattern;
+        p.param_wallRestitution = param_wallRestitution; p.param_wallFriction = param_wallFriction;
+        p.grid_cap = grid_cap;
+        return p;
+    }
+    void FromParams(const SphParams& p) {
+        param_h = p.param_h; param_mass = p.param_mass; param_restDensity = p.param_restDensity;
+        param_gasConstant = p.param_gasConstant; param_viscosity = p.param_viscosity;
+        param_gravityY = p.param_gravityY; param_gravityX = p.param_gravityX; param_gravityZ = p.param_gravityZ;
+        param_surfaceTension = p.param_surfaceTension; param_timeStep = p.param_timeStep;
+        param_pause = p.param_pause != 0; param_useJitter = p.param_useJitter != 0; param_jitterAmp = p.param_jitterAmp;
+        param_foamGen = p.param_foamGen; param_foamVelRef = p.param_foamVelRef;
+        param_boxCenter = MATH::Vec3(p.param_boxCenter[0], p.param_boxCenter[1], p.param_boxCenter[2]);
+        param_boxHalf = MATH::Vec3(p.param_boxHalf[0], p.param_boxHalf[1], p.param_boxHalf[2]);
+        param_boxEulerDeg = MATH::Vec3(p.param_boxEulerDeg[0], p.param_boxEulerDeg[1], p.param_boxEulerDeg[2]);
+        param_shapeType = p.param_shapeType;
+        param_shapeAux = MATH::Vec3(p.param_shapeAux[0], p.param_shapeAux[1], p.param_shapeAux[2]);
+        param_mixPattern = p.param_mixPattern; param_dyePattern = p.param_dyePattern;
+        param_wallRestitution = p.param_wallRestitution; param_wallFriction = p.param_wallFriction;
+        grid_cap = p.grid_cap;
+    }
+    void SetGrid(const SphGridInfo& g) {
+        gridSizeX = g.dims[0]; gridSizeY = g.dims[1]; gridSizeZ = g.dims[2]; numCells = g.numCells;
+        gridMinV = MATH::Vec3(g.gridMin[0], g.gridMin[1], g.gridMin[2]); cellSize = g.cellSize;
+    }
+    void RefreshGrid() {
+        SphGridInfo g;
+        if (!Check(sph_grid_info(engine, &g), "sph_grid_info")) SetGrid(g);
+    }
+    void AfterSpawn() {
+        SphParams p;
+        if (!Check(sph_get_params(engine, &p), "sph_get_params")) param_mass = p.param_mass;   // SPHFluid3D.cpp:92
+        particles.resize(sph_num_particles(engine));
+        Check(sph_initial_particles(engine, reinterpret_cast<SphParticle*>(particles.data()), particles.size()), "sph_initial_particles");
+        numFluids = 0;
+        for (const auto& q : particles) if (q.isGhost == 0) ++numFluids;                       // SPHFluid3D.cpp:338-339
+        box = param_boxHalf.x > param_boxHalf.y ? (param_boxHalf.x > param_boxHalf.z ? param_boxHalf.x : param_boxHalf.z)
+                                                : (param_boxHalf.y > param_boxHalf.z ? param_boxHalf.y : param_boxHalf.z);
+        RefreshGrid();
+        std::printf("Fluid particles: %zu\n", particles.size());
+    }
+    void Create() {
+        SphParams p = ToParams();
+        if (Check(sph_create(&engine, numParticles, &p, seed, stream), "sph_create")) return;
+        AfterSpawn();
+    }
+    bool Check(int rc, const char* what) {     // logs like Debug::FatalError (which only logs, Debug.cpp:54)
+        if (rc == SPH_OK) return false;
+        lastError = std::string(what) + ": " + sph_last_error();
+        std::fprintf(stderr, "SPHFluidGPU(HIP) %s\n", lastError.c_str());
+        return true;
+    }
+};
