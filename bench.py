@@ -29,15 +29,19 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults keep the timed window on the SPECIFIED workload (the seeded lattice state): the 35-unit
+    # column of configs[2] is not hydrostatically stable at k = 2000, g = -980 and collapses within a
+    # few hundred substeps, which turns the run into a different, denser workload
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
     ap.add_argument("--neighbor", type=int, default=0, help="0 LDS-tiled (default), 1 global gather")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
     ap.add_argument("--tile-config", type=int, default=-1, help="LDS/workgroup shape of the tiled pass (engine default if < 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="substeps of the CPU sample (0 = auto, about 10-30 s)")
-    ap.add_argument("--breakdown", action="store_true", help="extra untimed pass with per-kernel hipEvents")
+    ap.add_argument("--grid-build", default="sort", choices=["sort", "ll"], help="counting sort (default) or the reference's linked lists (A/B)")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the extra untimed pass with per-kernel hipEvents")
     return ap.parse_args()
 
 
@@ -125,6 +129,8 @@ def main():
     if args.tile_config >= 0:
         sim.set_option(104, args.tile_config)
     sim.set_option(pkg.SPH_OPT_AOS_MODE, 0 if args.aos == "eager" else 1)
+    if args.grid_build == "ll":
+        sim.set_option(pkg.SPH_OPT_GRID_BUILD, 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -151,7 +157,7 @@ def main():
         elapsed = float(tmax.item())
 
     breakdown = None
-    if args.breakdown or True:
+    if not args.no_breakdown:
         sim.set_option(pkg.SPH_OPT_TIMING, 1)
         sim.kernel_times(reset=True)
         nb = min(args.steps, 20)
@@ -192,11 +198,11 @@ def main():
                         + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")",
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
             "neighbor_kernel": "lds_tile" if args.neighbor == 0 else "global_gather", "aos": args.aos,
-            "pipeline": "bin+scan+scatter+rank -> sph(27-cell, OBB fused) -> AoS write-back" + (" + halo exchange" if args.gpus > 1 else ""),
+            "pipeline": ("bin+scan+scatter+rank -> sph(27-cell, OBB + AoS update fused)" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB + AoS update fused)") + (" + halo exchange" if args.gpus > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "k_sph_tile" if args.neighbor == 0 else "k_sph_gather",
+            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else ("k_sph_tile" if args.neighbor == 0 else "k_sph_gather")),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },

@@ -18,6 +18,7 @@ namespace sph {
 struct SimK {
     // SPHFluid.comp uniforms + derived kernel coefficients (:42-64)
     float h, h2, poly6C, spikyC, viscC;
+    float h2hi;   // h2 * (1 + 1e-6): r2 >= h2hi implies sqrt(r2) >= h, a cheap superset filter for the force sweep
     float mass, negMass, rho0, halfRho0, kgas, visc, negSigma;
     float gravx, gravy, gravz;
     float dt, maxSpeed, foamGen, foamVelRefMax;

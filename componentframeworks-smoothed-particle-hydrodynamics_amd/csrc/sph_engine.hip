@@ -84,6 +84,7 @@ struct SphEngine {
     // grid / sort scratch
     uint32_t *d_cellOf = nullptr, *d_slotOf = nullptr, *d_order = nullptr;
     uint32_t *d_slowSlots = nullptr, *d_slowCount = nullptr;   // exceptional targets of the tiled pass
+    int32_t *d_llNext = nullptr, *d_llCell = nullptr, *d_llKey = nullptr;   // linked-list A/B variant (particleNext, particleCell, cellKey)
     uint2* d_tmp = nullptr;
     uint32_t *d_cellCount = nullptr, *d_cellStart = nullptr, *d_blockSums = nullptr;
     int32_t* d_dbg = nullptr;
@@ -153,6 +154,7 @@ void free_particle_buffers(SphEngine* e) {
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
     dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt);
+    dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
     e->cap = 0;
 }
 void free_grid_buffers(SphEngine* e) {
@@ -288,11 +290,32 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         k.gz = e->z1 - e->z0 + 2; k.numCells = k.gx * k.gy * k.gz; k.zoff = e->z0 - 1;
     }
     if ((rc = import_state(e))) return rc;
-    if ((rc = build_grid(e, k))) return rc;                                 // :449-468
     const int n = (int)(e->slab ? e->nSlots : e->n);
     StateIn in{e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur]};
     const int nx = e->cur ^ 1;
-    StateOut out{e->d_pos[nx], e->d_vel[nx], e->d_rp[nx], e->d_foam[nx], e->d_acc};
+    const bool fuseAos = !e->slab && e->optAos == 0 && e->aosValid;   // the array is current: keep it current from the SPH pass
+    StateOut out{e->d_pos[nx], e->d_vel[nx], e->d_rp[nx], e->d_foam[nx], e->d_acc, fuseAos ? e->d_aos : nullptr, e->idBase};
+    if (e->optGridBuild == 1) {
+        // ---- A/B variant: the reference's atomicExchange linked lists (no sorting) ----
+        if (e->slab) return fail(SPH_ERR_STATE, "the linked-list variant is single-GPU only");
+        if (!e->d_llNext) {
+            if ((rc = dev_alloc(&e->d_llNext, e->cap)) || (rc = dev_alloc(&e->d_llCell, e->cap)) || (rc = dev_alloc(&e->d_llKey, e->cap))) return rc;
+        }
+        int32_t* cellHead = reinterpret_cast<int32_t*>(e->d_cellStart);      // C+1 ints, reused as cellHead
+        {
+            Timed t(e, SPH_K_SCAN);
+            hipLaunchKernelGGL(k_ll_clear, dim3(blocks_for((size_t)k.numCells)), dim3(kBlock), 0, e->stream, cellHead, k.numCells);
+        }
+        if (n) {
+            {
+                Timed t(e, SPH_K_BIN);
+                hipLaunchKernelGGL(k_ll_build, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in.pos, cellHead, e->d_llNext, e->d_llCell, e->d_llKey, n);
+            }
+            Timed t(e, SPH_K_SPH);
+            hipLaunchKernelGGL(k_sph_ll, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, cellHead, e->d_llNext, n);
+        }
+    } else {
+    if ((rc = build_grid(e, k))) return rc;                                 // :449-468
     if (n) {                                                                // :470-509 (SPH + OBB fused)
         if (e->optNeighbor == 1) {
             Timed t(e, SPH_K_SPH);
@@ -313,15 +336,16 @@ int dispatch_one(SphEngine* e, float overrideDt) {
             }
         }
     }
+    }
     HIP_TRY(hipGetLastError());
     e->cur = nx;
-    e->accValid = true;
-    e->aosValid = false;
+    e->accValid = !fuseAos;
+    e->aosValid = fuseAos;
     if (e->slab) {   // the sorted output holds exactly the live particles: remember their count on the device
         HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, e->d_cellStart + k.numCells, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
         return SPH_OK;
     }
-    if (e->optAos == 0) return writeback(e);
+    if (e->optAos == 0 && !e->aosValid) return writeback(e);
     return SPH_OK;
 }
 
@@ -454,7 +478,7 @@ int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
     case SPH_OPT_NEIGHBOR_KERNEL: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optNeighbor = value; break;
-    case SPH_OPT_GRID_BUILD: if (value != 0) return fail(SPH_ERR_ARG, "linked-list grid build not implemented yet"); e->optGridBuild = value; break;
+    case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
     case SPH_OPT_DEBUG: e->tile.debugFlags = value; break;

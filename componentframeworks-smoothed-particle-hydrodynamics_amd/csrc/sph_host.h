@@ -99,7 +99,7 @@ inline void make_simk(const SphParams& p, const SphGridInfo& g, float dt, SimK& 
     const float h = p.param_h;
     const float h2 = h * h, h3 = h2 * h, h6 = h3 * h3, h9 = h6 * h3;
     const float pi_f = 3.141592653589f;               // literal of SPHFluid.comp:45,53,60
-    k.h = h; k.h2 = h2;
+    k.h = h; k.h2 = h2; k.h2hi = h2 * 1.000001f;
     k.poly6C = 315.0f / ((64.0f * pi_f) * h9);
     k.spikyC = -45.0f / (pi_f * h6);
     k.viscC = 45.0f / (pi_f * h6);

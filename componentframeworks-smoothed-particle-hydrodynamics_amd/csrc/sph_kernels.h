@@ -209,7 +209,29 @@ struct StateOut {
     float2* __restrict__ rp;
     float* __restrict__ foam;
     float4* __restrict__ acc;
+    // eager AoS mode: the public 80-byte array is updated straight from the SPH pass (the values
+    // are in registers here); nullptr in lazy / z-slab mode, where k_writeback runs on demand
+    SphParticle* __restrict__ aos;
+    uint32_t idBase;
 };
+
+// Fields SPHFluid.comp / OBBConstraints.comp change, written into the record of particle `id`.
+__device__ __forceinline__ void aos_write_fluid(SphParticle* __restrict__ aos, uint32_t id, float px, float py, float pz,
+                                                float vx, float vy, float vz, float ax, float ay, float az,
+                                                float rho, float prs, float foam) {
+    float* rec = reinterpret_cast<float*>(aos + id);
+    rec[0] = px; rec[1] = py; rec[2] = pz;
+    rec[4] = vx; rec[5] = vy; rec[6] = vz;
+    *reinterpret_cast<float4*>(rec + 8) = make_float4(ax, ay, az, 0.0f);
+    rec[12] = rho; rec[13] = prs; rec[14] = foam;
+}
+// Ghost branch of SPHFluid.comp:72-83 for an ACTIVE ghost: vel = acc = vec4(0), density = rho0, pressure = 0.
+__device__ __forceinline__ void aos_write_active_ghost(SphParticle* __restrict__ aos, uint32_t id, float rho0) {
+    float* rec = reinterpret_cast<float*>(aos + id);
+    *reinterpret_cast<float4*>(rec + 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    *reinterpret_cast<float4*>(rec + 8) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    rec[12] = rho0; rec[13] = 0.0f;
+}
 
 // Ghost branch of SPHFluid.comp:72-83 and the common epilogue (OBB + store).
 __device__ __forceinline__ void store_particle(const SimK& k, const StateOut& out, int s, uint32_t flags, uint32_t id,
@@ -219,7 +241,8 @@ __device__ __forceinline__ void store_particle(const SimK& k, const StateOut& ou
     out.vel[s] = make_float4(o.vx, o.vy, o.vz, bitsf(id));
     out.rp[s] = make_float2(o.rho, o.prs);
     out.foam[s] = foamOut;
-    out.acc[s] = make_float4(o.ax, o.ay, o.az, 0.0f);
+    if (out.aos) aos_write_fluid(out.aos, id - out.idBase, o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+    else out.acc[s] = make_float4(o.ax, o.ay, o.az, 0.0f);
 }
 
 // SPHFluid.comp main() for the particle in sorted slot s, neighbours gathered from global
@@ -241,7 +264,8 @@ __device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in,
         out.vel[s] = make_float4(o.vx, o.vy, o.vz, V.w);
         out.rp[s] = make_float2(o.rho, o.prs);
         out.foam[s] = foamIn;
-        out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
+        else out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
     const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
@@ -346,6 +370,91 @@ __global__ __launch_bounds__(kBlock) void k_debug_particle_cell(SimK k, const fl
     particleCell[fbits(vel[s].w) - idBase] = (cz * k.gy + cy) * k.gx + cx;
 }
 
+
+// ======================= linked-list grid build (A/B variant, SPH_OPT_GRID_BUILD = 1) ==========
+// The reference's own scheme, kept for the BASELINE configs[1] comparison: ClearGrid.comp writes
+// cellHead = -1, BuildGrid.comp pushes every particle on its cell's list with an atomic exchange
+// and also writes particleCell / cellKey; the SPH pass then chases cellHead -> particleNext.
+// Particles are never sorted in this mode (slot i stays particle i).  List order is the atomic
+// arrival order, so fp32 sums are NOT reproducible here -- exactly the reference's behaviour; the
+// parity tests for this variant use a tolerance instead of bit equality.
+__global__ __launch_bounds__(kBlock) void k_ll_clear(int32_t* __restrict__ cellHead, int numCells) {
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c < numCells) cellHead[c] = -1;                               // ClearGrid.comp:9
+}
+__global__ __launch_bounds__(kBlock) void k_ll_build(SimK k, const float4* __restrict__ pos, int32_t* __restrict__ cellHead,
+                                                     int32_t* __restrict__ particleNext, int32_t* __restrict__ particleCell,
+                                                     int32_t* __restrict__ cellKey, int n) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos[i];
+    const int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
+    const int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
+    const int cz = cell_z_local(k, p.z);
+    const int cell = (cz * k.gy + cy) * k.gx + cx;                    // BuildGrid.comp:19,27
+    particleCell[i] = cell;                                           // :29
+    cellKey[i] = cell;                                                // :30
+    particleNext[i] = atomicExch(&cellHead[cell], i);                 // :31-32
+}
+
+template <class F>
+__device__ __forceinline__ void for_each_listed(const SimK& k, int cx, int cy, int cz, const int32_t* __restrict__ cellHead,
+                                                const int32_t* __restrict__ particleNext, F&& f) {
+    for (int dx = -1; dx <= 1; ++dx)                                  // the shader's own nesting, SPHFluid.comp:91-93
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+                if (nx < 0 || ny < 0 || nz < 0 || nx >= k.gx || ny >= k.gy || nz >= k.gz) continue;
+                int j = cellHead[nx + k.gx * (ny + k.gy * nz)];
+                while (j != -1) { f(j); j = particleNext[j]; }
+            }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sph_ll(SimK k, StateIn in, StateOut out, const int32_t* __restrict__ cellHead,
+                                                   const int32_t* __restrict__ particleNext, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 P = in.pos[i], V = in.vel[i];
+    const float2 RP = in.rp[i];
+    const float foamIn = in.foam[i];
+    const uint32_t flags = fbits(P.w), id = fbits(V.w);
+    Own o;
+    own_reset(o);
+    o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = RP.x; o.prs = RP.y;
+    if (flags & F_GHOST1) {
+        if (!(flags & F_INACTIVE)) { o.vx = o.vy = o.vz = 0.0f; o.rho = k.rho0; o.prs = 0.0f; }
+        out.pos[i] = P;
+        out.vel[i] = make_float4(o.vx, o.vy, o.vz, V.w);
+        out.rp[i] = make_float2(o.rho, o.prs);
+        out.foam[i] = foamIn;
+        if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
+        else out.acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
+    const int cy = cell_axis(P.y, k.gminy, k.cellSize, k.gy);
+    const int cz = cell_z_local(k, P.z);
+    for_each_listed(k, cx, cy, cz, cellHead, particleNext, [&](int j) {
+        const float4 J = in.pos[j];
+        pair_density(k, o, J.x, J.y, J.z);
+    });
+    finish_density(k, o);
+    for_each_listed(k, cx, cy, cz, cellHead, particleNext, [&](int j) {
+        if (j == i) return;
+        const float4 J = in.pos[j], JV = in.vel[j];
+        const float2 JR = in.rp[j];
+        pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x, JR.y);
+    });
+    integrate(k, o);
+    for_each_listed(k, cx, cy, cz, cellHead, particleNext, [&](int j) {
+        if (j == i) return;
+        const float4 J = in.pos[j], JV = in.vel[j];
+        const float2 JR = in.rp[j];
+        pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x);
+    });
+    const float foamOut = finish_particle(k, o, foamIn);
+    store_particle(k, out, i, flags, id, o, foamOut);
+}
 
 // ======================= z-slab (multi-GPU) support ==========================================
 // 48-byte record that crosses ranks: a migrant (flags without F_HALO: the receiver owns it)

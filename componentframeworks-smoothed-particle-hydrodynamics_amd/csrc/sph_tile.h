@@ -70,6 +70,7 @@ struct TileLdsT {
     uint16_t clLen[kMaxCells];       // candidates of the cell, 0xFFFF = does not fit the mask
     uint16_t clSelf[kMaxCells];      // list position of the cell's own first particle
     int sliceTz;
+    int maxLen;                      // longest 27-cell candidate list of the tile (slice planning)
     static_assert((kMaxHaloCells + kMaxRows) * 4 <= kListPool * 2, "prologue cellStart copy must fit the list pool");
 };
 
@@ -129,10 +130,10 @@ __device__ __forceinline__ float4 lds_f4(const void* base, uint32_t byteOff) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byteOff);
 }
 
-// sweep 1 over 8 candidates whose byte offsets are packed in `ix`: density + 8 mask bits
-// (first candidate = bit 7).
-template <class LDS>
-__device__ __forceinline__ uint32_t scan8(const SimK& k, const LDS& L, Own& o, float h2list, uint4 ix) {
+// 8 candidates whose byte offsets are packed in `ix` against the query point (qx,qy,qz):
+// 8 mask bits (first candidate = bit 7) for r2 < thr2 and, when DENS, the density sum of sweep 1.
+template <bool DENS, class LDS>
+__device__ __forceinline__ uint32_t scan8(const SimK& k, const LDS& L, Own& o, float qx, float qy, float qz, float thr2, uint4 ix) {
     const uint32_t o0 = ix.x & 0xffffu, o1 = ix.x >> 16, o2 = ix.y & 0xffffu, o3 = ix.y >> 16;
     const uint32_t o4 = ix.z & 0xffffu, o5 = ix.z >> 16, o6 = ix.w & 0xffffu, o7 = ix.w >> 16;
     const float4 J0 = lds_f4(L.pos, o0), J1 = lds_f4(L.pos, o1), J2 = lds_f4(L.pos, o2), J3 = lds_f4(L.pos, o3);
@@ -140,20 +141,64 @@ __device__ __forceinline__ uint32_t scan8(const SimK& k, const LDS& L, Own& o, f
     uint32_t bits = 0;
 #define SPH_SCAN1(J)                                                       \
     {                                                                      \
-        const float dx = o.px - J.x, dy = o.py - J.y, dz = o.pz - J.z;     \
+        const float dx = qx - J.x, dy = qy - J.y, dz = qz - J.z;           \
         const float r2 = dot3(dx, dy, dz, dx, dy, dz);                     \
-        const float tt = fmaxf(k.h2 - r2, 0.0f);                           \
-        const float w = k.poly6C * ((tt * tt) * tt);                       \
-        o.dens = fmaf(k.mass, w, o.dens);                                  \
-        bits = (bits << 1) | ((r2 < h2list) ? 1u : 0u);                    \
+        if (DENS) {                                                        \
+            const float tt = fmaxf(k.h2 - r2, 0.0f);                       \
+            const float w = k.poly6C * ((tt * tt) * tt);                   \
+            o.dens = fmaf(k.mass, w, o.dens);                              \
+        }                                                                  \
+        bits = (bits << 1) | ((r2 < thr2) ? 1u : 0u);                      \
     }
     SPH_SCAN1(J0) SPH_SCAN1(J1) SPH_SCAN1(J2) SPH_SCAN1(J3) SPH_SCAN1(J4) SPH_SCAN1(J5) SPH_SCAN1(J6) SPH_SCAN1(J7)
 #undef SPH_SCAN1
     return bits;
 }
 
+// Groups [g0, g1) (8 candidates each, g1 - g0 <= 12) of the list at clp: candidate kk of the
+// chunk ends up at bit 8*(g1-g0)-1-kk of the 96-bit register m2:m1:m0.
+template <bool DENS, class LDS>
+__device__ __forceinline__ void scan_chunk(const SimK& k, const LDS& L, Own& o, const uint16_t* clp, int g0, int g1,
+                                           float qx, float qy, float qz, float thr2, uint32_t& m0, uint32_t& m1, uint32_t& m2) {
+    m0 = m1 = m2 = 0;
+    uint4 ix = *reinterpret_cast<const uint4*>(clp + 8 * g0);
+    for (int g = g0; g < g1; ++g) {
+        const uint4 nx = *reinterpret_cast<const uint4*>(clp + 8 * (g + 1));   // padded / next list: always mapped
+        const uint32_t b = scan8<DENS>(k, L, o, qx, qy, qz, thr2, ix);
+        m2 = (m2 << 8) | (m1 >> 24);
+        m1 = (m1 << 8) | (m0 >> 24);
+        m0 = (m0 << 8) | b;
+        ix = nx;
+    }
+}
+
+// Visit the set bits of m2:m1:m0 from the top (= ascending candidate order); f(byteOffset).
+template <class F>
+__device__ __forceinline__ int walk_chunk(const uint16_t* clp, int g0, int g1, uint32_t m0, uint32_t m1, uint32_t m2, F&& f) {
+    const uint32_t topBit = (uint32_t)(8 * (g1 - g0) - 1);
+    const uint16_t* cp = clp + 8 * g0;
+    int trips = 0;
+    while (m2) {
+        const int p = 31 - __clz((int)m2);
+        m2 &= ~(1u << p);
+        f((uint32_t)cp[topBit - (64u + (uint32_t)p)]);
+        ++trips;
+    }
+    uint64_t mm = ((uint64_t)m1 << 32) | (uint64_t)m0;
+    while (mm) {
+        const int p = 63 - __clzll((long long)mm);
+        mm &= ~(1ull << p);
+        f((uint32_t)cp[topBit - (uint32_t)p]);
+        ++trips;
+    }
+    return trips;
+}
+
+// A sub-box of a tile: cells [x0,x0+tx) x [y0,y0+ty) x [z0,z0+tz) (absolute), plus where it sits in
+// the tile's LDS cellStart copy (row pitch csW, csHY rows per z layer, offset csX/csY/csZ in cells).
 struct SliceGeo {
-    int x0, y0, z0, tx, ty, tz, HX, HY;
+    int x0, y0, z0, tx, ty, tz;
+    int csW, csHY, csX, csY, csZ;
 };
 
 // Targets the fast path does not take (cell list overflow, sweep-3 displacement beyond the
@@ -181,17 +226,17 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, StateIn in, StateOu
         sph_gather_one(k, in, out, order, cellStart, (int)q.slots[i]);
 }
 
-// One z-slice of a tile.  Uniform control flow up to the target loop; contains __syncthreads().
-// When csInLds, L.cl holds (as uint32_t cs[]) the tile's cellStart copy: cs[r * (HX + 1) + hx]
-// for whole-tile halo row r and halo column hx = 0..HX (column HX = one past the row's end).
+// One sub-box of a tile.  Uniform control flow up to the target loop; contains __syncthreads().
+// When csInLds, L.cl holds (as uint32_t cs[]) the tile's cellStart copy: cs[r * csW + hx] for
+// whole-tile halo row r and halo column hx (the last column = one past the row's end).
 template <bool STAMP, class CFG>
-__device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int dbg, const SliceGeo& G, int rowBase, bool csInLds,
+__device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int dbg, const SliceGeo& G, bool csInLds,
                                            const StateIn& in, const StateOut& out, const uint32_t* __restrict__ order,
                                            const uint32_t* __restrict__ cellStart, const SlowQueue& slowq, unsigned long long* st) {
     constexpr int kTileThreads = CFG::kThreads, kMaxCand = CFG::kMaxCand, kListPool = CFG::kListPool;
     const int tid = threadIdx.x;
     const int x0 = G.x0, y0 = G.y0, z0 = G.z0, tx = G.tx, ty = G.ty, tz = G.tz;
-    const int HX = G.HX, HY = G.HY, HZ = tz + 2;
+    const int HX = tx + 2, HY = ty + 2, HZ = tz + 2;
     const int R = HY * HZ;
     const int xlo = max(x0 - 1, 0), xhi = min(x0 + tx, k.gx - 1);      // staged x range (inclusive)
     unsigned long long c0 = stamp_now<STAMP>();
@@ -200,8 +245,8 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
     // cellStart of halo cell (hx, r) of this slice, hx in [0, HX]; cells outside the grid
     // collapse onto the nearest in-grid boundary so that differences give 0 particles.
     auto cs_at = [&](int r, int hx) -> uint32_t {
-        if (csInLds) return cs[(rowBase + r) * (HX + 1) + hx];
         const int hy = r % HY, hz = r / HY;
+        if (csInLds) return cs[((G.csZ + hz) * G.csHY + G.csY + hy) * G.csW + G.csX + hx];
         const int yy = y0 - 1 + hy, zz = z0 - 1 + hz;
         if (yy < 0 || yy >= k.gy || zz < 0 || zz >= k.gz) return 0u;
         const int xg = min(max(x0 - 1 + hx, xlo), xhi + 1);
@@ -281,9 +326,9 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
     const int nCells = tx * IR;
     // list stride: an odd number of 16-B slots (8 entries each) so that the b128 index reads of
     // neighbouring cells fall on different bank groups
-    int CLs = min(kListPool / max(nCells, 1), 104) & ~7;
+    int CLs = min(kListPool / max(nCells, 1), 1016) & ~7;
     if (!((CLs >> 3) & 1)) CLs -= 8;
-    const int cap = min(CLs, kMaskBits);
+    const int cap = CLs;                                       // lists longer than one 96-bit mask are processed in chunks
     if (tid < 64) {
         uint32_t cnt = 0;
         if (tid < IR) {
@@ -372,20 +417,18 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         const float hl = k.h + slack;
         const float h2list = hl * hl;
 
-        // ---- sweep 1 (mask path), uniform over the wave: candidate kk ends up at bit
-        //      8*groups-1-kk of the 96-bit register m2:m1:m0 ----
+        // ---- wave-uniform plan: groups of 8 candidates in the longest list of this wave ----
         const int groups = (__builtin_amdgcn_readfirstlane((int)wave_max_u32(useMask ? len : 0u)) + 7) >> 3;
         const uint16_t* clp = &L.cl[c * CLs];
+        const bool dense = groups > 12;                            // more candidates than one 96-bit mask holds
         uint32_t m0 = 0, m1 = 0, m2 = 0;
-        {
-            uint4 ix = *reinterpret_cast<const uint4*>(clp);
-            for (int g = 0; g < groups; ++g) {
-                const uint4 nx = *reinterpret_cast<const uint4*>(clp + 8 * (g + 1));   // padded / next list: always mapped
-                const uint32_t b = scan8(k, L, o, h2list, ix);
-                m2 = (m2 << 8) | (m1 >> 24);
-                m1 = (m1 << 8) | (m0 >> 24);
-                m0 = (m0 << 8) | b;
-                ix = nx;
+        // sweep 1: density over every candidate; a short list also yields the neighbour mask
+        if (!dense) {
+            scan_chunk<true>(k, L, o, clp, 0, groups, o.px, o.py, o.pz, h2list, m0, m1, m2);
+        } else {
+            for (int g0 = 0; g0 < groups; g0 += 12) {
+                uint32_t t0, t1, t2;
+                scan_chunk<true>(k, L, o, clp, g0, min(g0 + 12, groups), o.px, o.py, o.pz, k.h2, t0, t1, t2);
             }
         }
         const unsigned long long w1 = stamp_now<STAMP>();
@@ -404,75 +447,68 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
                 out.vel[s] = make_float4(gvx, gvy, gvz, V.w);
                 out.rp[s] = make_float2(grho, gprs);
                 out.foam[s] = foamIn;
-                out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
+                else out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             continue;
         }
-        if (!useMask) {                                            // cell list overflow: exact path in k_sph_slow
+        if (!useMask) {                                            // list does not fit the pool: exact path in k_sph_slow
             if (STAMP && valid) stamp_add<STAMP>(st, TS_SLOW_LANES, 1);
             slow_push(slowq, valid, (uint32_t)s);
             continue;
         }
         finish_density(k, o);
-        const uint32_t topBit = (uint32_t)(8 * groups - 1);
-        {   // the particle itself is in its own cell's list: drop its bit (sweeps 2/3 skip self)
-            const uint32_t ks = (uint32_t)L.clSelf[c] + (li - (uint32_t)L.cellOff[r * HX + hx]);
-            const uint32_t B = topBit - ks;
-            const uint32_t bit = 1u << (B & 31u);
-            const uint32_t w = B >> 5;
-            m0 &= ~(w == 0 ? bit : 0u); m1 &= ~(w == 1 ? bit : 0u); m2 &= ~(w == 2 ? bit : 0u);
-        }
-        int trips2 = 0;
-        // sweep 2: forces over the set bits, highest bit first = ascending candidate order
-        {
-            uint32_t mt = m2;
-            while (mt) {
-                const int p = 31 - __clz((int)mt);
-                mt &= ~(1u << p);
-                const uint32_t off = clp[topBit - (64u + (uint32_t)p)];
-                const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
-                if (J.w > 0.0f) pair_force_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w);
-                ++trips2;
+        const uint32_t ks = (uint32_t)L.clSelf[c] + (li - (uint32_t)L.cellOff[r * HX + hx]);   // own position in the list
+        auto drop_self = [&](int g0, int g1, uint32_t& a0, uint32_t& a1, uint32_t& a2) {
+            const uint32_t lo = (uint32_t)(8 * g0), hi = (uint32_t)(8 * g1);
+            if (ks >= lo && ks < hi) {
+                const uint32_t B = (hi - lo - 1u) - (ks - lo);
+                const uint32_t bit = 1u << (B & 31u);
+                const uint32_t w = B >> 5;
+                a0 &= ~(w == 0 ? bit : 0u); a1 &= ~(w == 1 ? bit : 0u); a2 &= ~(w == 2 ? bit : 0u);
             }
-            uint64_t mm = ((uint64_t)m1 << 32) | (uint64_t)m0;
-            while (mm) {
-                const int p = 63 - __clzll((long long)mm);
-                mm &= ~(1ull << p);
-                const uint32_t off = clp[topBit - (uint32_t)p];
-                const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
-                if (J.w > 0.0f) pair_force_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w);
-                ++trips2;
+        };
+        auto force_at = [&](uint32_t off) {
+            const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
+            if (J.w > 0.0f) pair_force_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w);
+        };
+        auto xsph_at = [&](uint32_t off) {
+            const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
+            if (J.w > 0.0f) pair_xsph_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w);
+        };
+        int trips2 = 0;
+        // sweep 2: forces, ascending candidate order
+        if (!dense) {
+            drop_self(0, groups, m0, m1, m2);
+            trips2 = walk_chunk(clp, 0, groups, m0, m1, m2, force_at);
+        } else {
+            for (int g0 = 0; g0 < groups; g0 += 12) {
+                const int g1 = min(g0 + 12, groups);
+                uint32_t t0, t1, t2;
+                scan_chunk<false>(k, L, o, clp, g0, g1, ex, ey, ez, k.h2hi, t0, t1, t2);
+                drop_self(g0, g1, t0, t1, t2);
+                trips2 += walk_chunk(clp, g0, g1, t0, t1, t2, force_at);
             }
         }
         integrate(k, o);
         const unsigned long long w2 = stamp_now<STAMP>();
-        // sweep 3: XSPH with the updated own state; the mask is valid only if the
-        // displacement stayed inside the slack it was built with.
+        // sweep 3: XSPH with the updated own state.  The sweep-1 mask stays valid only if the
+        // displacement stayed inside the slack it was built with; otherwise (and for long
+        // lists) the candidates are re-scanned from LDS against the new position.
         const float mx = o.px - ex, my = o.py - ey, mz = o.pz - ez;
         const float moved2 = dot3(mx, my, mz, mx, my, mz);
         const float lim = 0.98f * slack;
-        const bool rescan = !(moved2 <= lim * lim) || (dbg & 2);
-        if (rescan) {                                              // mask no longer covers sweep 3: redo in k_sph_slow
-            if (STAMP && valid) stamp_add<STAMP>(st, TS_RESCAN_LANES, 1);
-            slow_push(slowq, valid, (uint32_t)s);
-            continue;
-        }
-        {
-            uint32_t mt = m2;
-            while (mt) {
-                const int p = 31 - __clz((int)mt);
-                mt &= ~(1u << p);
-                const uint32_t off = clp[topBit - (64u + (uint32_t)p)];
-                const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
-                if (J.w > 0.0f) pair_xsph_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w);
-            }
-            uint64_t mm = ((uint64_t)m1 << 32) | (uint64_t)m0;
-            while (mm) {
-                const int p = 63 - __clzll((long long)mm);
-                mm &= ~(1ull << p);
-                const uint32_t off = clp[topBit - (uint32_t)p];
-                const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
-                if (J.w > 0.0f) pair_xsph_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w);
+        const bool maskOk = !dense && (moved2 <= lim * lim) && !(dbg & 2);
+        if (!__any(!maskOk)) {                                     // uniform over the lanes still active
+            (void)walk_chunk(clp, 0, groups, m0, m1, m2, xsph_at);
+        } else {
+            if (STAMP && valid && !maskOk) stamp_add<STAMP>(st, TS_RESCAN_LANES, 1);
+            for (int g0 = 0; g0 < groups; g0 += 12) {
+                const int g1 = min(g0 + 12, groups);
+                uint32_t t0, t1, t2;
+                scan_chunk<false>(k, L, o, clp, g0, g1, o.px, o.py, o.pz, k.h2, t0, t1, t2);
+                drop_self(g0, g1, t0, t1, t2);
+                (void)walk_chunk(clp, g0, g1, t0, t1, t2, xsph_at);
             }
         }
         const unsigned long long w3 = stamp_now<STAMP>();
@@ -532,42 +568,74 @@ __global__ __launch_bounds__(CFG::kThreads) void k_sph_tile(SimK k, TileGeom g, 
     if (tid == 0) {
         L.pos[kMaxCand] = make_float4(1e18f, 1e18f, 1e18f, 0.0f);   // sentinel: never within any radius
         L.vel[kMaxCand] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        L.maxLen = 0;
     }
     __syncthreads();
-    // ---- plan: thickest z-slicing whose every slice (plus halo) fits kMaxCand and kMaxCells ----
-    if (tid < 64) {
-        // interior cells per slice: at most kMaxCells and few enough for list strides >= 72 entries
-        int sp = max(1, min(g.tz, min(kMaxCells, CFG::kListPool / 72) / (g.tx * g.ty)));
-        const uint32_t cnt = (tid < HY * HZ) ? (cs[tid * W + HX] - cs[tid * W]) : 0u;
-        const uint32_t total = (uint32_t)__shfl((int)wave_incl_scan(cnt), 63, 64);
-        if (tid == 0) {
-            if (!(sp == g.tz && total <= (uint32_t)kMaxCand)) {     // rare: dense tile, find the thickest slicing that fits
-                while (sp > 1) {
-                    bool ok = true;
-                    for (int zs = 0; zs < g.tz && ok; zs += sp) {
-                        const int hz1 = min(zs + sp, g.tz) + 2;           // halo layers [zs, hz1)
-                        uint32_t sum = 0;
-                        for (int r = zs * HY; r < hz1 * HY; ++r) sum += cs[r * W + HX] - cs[r * W];
-                        ok = sum <= (uint32_t)kMaxCand;
-                    }
-                    if (ok) break;
-                    sp = (sp + 1) >> 1;
+    {   // longest candidate list among the tile's cells (from the cellStart copy)
+        int mx = 0;
+        for (int c = tid; c < g.tx * g.ty * g.tz; c += kTileThreads) {
+            const int ix = c % g.tx, iy = (c / g.tx) % g.ty, iz = c / (g.tx * g.ty);
+            int len = 0;
+            for (int dz = 0; dz < 3; ++dz)
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = (iz + dz) * HY + iy + dy;
+                    len += (int)(cs[r * W + ix + 3] - cs[r * W + ix]);
                 }
+            mx = max(mx, len);
+        }
+        mx = (int)wave_max_u32((uint32_t)mx);
+        if ((tid & 63) == 0 && mx > 0) atomicMax(&L.maxLen, mx);
+    }
+    __syncthreads();
+    // ---- plan: the largest sub-box (halved in z, then y, then x) such that every sub-box of
+    //      the tile fits: staged particles <= kMaxCand, cells <= kMaxCells, lists fit the pool.
+    //      The common case (whole tile) needs one pass; dense tiles iterate, all threads in step. ----
+    int sx = g.tx, sy = g.ty, sz = g.tz;
+    {
+        const int needStride = max(72, ((L.maxLen + 7) & ~7) + 16);
+        const int maxCellsPerBox = max(1, min(kMaxCells, CFG::kListPool / needStride));
+        for (;;) {
+            while (sx * sy * sz > maxCellsPerBox) {
+                if (sz > 1) sz = (sz + 1) >> 1; else if (sy > 1) sy = (sy + 1) >> 1; else if (sx > 1) sx = (sx + 1) >> 1; else break;
             }
-            L.sliceTz = sp;
+            if (tid == 0) L.sliceTz = 0;
+            __syncthreads();
+            const int nbx = (g.tx + sx - 1) / sx, nby = (g.ty + sy - 1) / sy, nbz = (g.tz + sz - 1) / sz;
+            bool over = false;
+            for (int b = tid; b < nbx * nby * nbz; b += kTileThreads) {
+                const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
+                const int xs = bx * sx, ys = by * sy, zs = bz * sz;
+                const int ex = min(xs + sx, g.tx), ey = min(ys + sy, g.ty), ez = min(zs + sz, g.tz);
+                uint32_t sum = 0;
+                for (int hz = zs; hz < ez + 2; ++hz)
+                    for (int hy = ys; hy < ey + 2; ++hy) sum += cs[(hz * HY + hy) * W + ex + 2] - cs[(hz * HY + hy) * W + xs];
+                over = over || (sum > (uint32_t)kMaxCand);
+            }
+            if (over) L.sliceTz = 1;                                   // benign race: any writer writes 1
+            __syncthreads();
+            const bool bad = L.sliceTz != 0;
+            __syncthreads();
+            if (!bad) break;
+            if (sz > 1) sz = (sz + 1) >> 1; else if (sy > 1) sy = (sy + 1) >> 1; else if (sx > 1) sx = (sx + 1) >> 1;
+            else break;                                                // single cells still overflow: those go to the slow queue
         }
     }
-    __syncthreads();
-    const int sl = L.sliceTz;
     if (STAMP && tid == 0) { stamp_add<STAMP>(st, TS_PROLOGUE, stamp_now<STAMP>() - k0); stamp_add<STAMP>(st, TS_TILES, 1); }
-    for (int zs = 0; zs < g.tz; zs += sl) {
-        SliceGeo G;
-        G.x0 = x0; G.y0 = y0; G.z0 = z0 + zs; G.tx = g.tx; G.ty = g.ty; G.tz = min(sl, g.tz - zs); G.HX = HX; G.HY = HY;
-        // the LDS cellStart copy is overwritten by the first slice's lists; later slices (dense
-        // tiles only) read cellStart from global memory again
-        tile_slice<STAMP, CFG>(L, k, g.debugFlags, G, zs * HY, zs == 0, in, out, order, cellStart, slowq, st);
-        __syncthreads();
-    }
+    bool first = true;
+    for (int zs = 0; zs < g.tz; zs += sz)
+        for (int ys = 0; ys < g.ty; ys += sy)
+            for (int xs = 0; xs < g.tx; xs += sx) {
+                SliceGeo G;
+                G.x0 = x0 + xs; G.y0 = y0 + ys; G.z0 = z0 + zs;
+                G.tx = min(sx, g.tx - xs); G.ty = min(sy, g.ty - ys); G.tz = min(sz, g.tz - zs);
+                G.csW = W; G.csHY = HY; G.csX = xs; G.csY = ys; G.csZ = zs;
+                if (G.x0 >= k.gx || G.y0 >= k.gy || G.z0 >= k.gz) continue;   // sub-box outside the grid (clipped tile)
+                // the LDS cellStart copy is overwritten by the first sub-box's lists; later ones
+                // (dense tiles only) read cellStart from global memory again
+                tile_slice<STAMP, CFG>(L, k, g.debugFlags, G, first, in, out, order, cellStart, slowq, st);
+                first = false;
+                __syncthreads();
+            }
     if (STAMP && tid == 0) stamp_add<STAMP>(st, TS_TOTAL, stamp_now<STAMP>() - k0);
 }
 

@@ -270,3 +270,55 @@ def test_full_size_properties_config3(pkg):
     assert np.all(np.abs(out["pos"][:, :3]) <= half[None, :] + 1e-4)
     assert np.linalg.norm(out["vel"][:, :3], axis=1).max() <= 0.4 * 0.28 / 1e-3 * (1 + 1e-6)
     assert out["density"].min() >= 500.0 and np.isfinite(out["pos"]).all()
+
+
+@pytest.mark.parametrize("scale", [0.75, 0.6, 0.45])
+def test_dense_fluid_stays_on_the_tiled_path(pkg, oracle, scale):
+    """Compressed fluid: 2.4x / 4.6x / 11x the lattice density, i.e. 27-cell candidate lists far
+    beyond one 96-bit mask.  The tiled pass thins its slices, widens the list stride and walks
+    the lists in 96-candidate chunks; results stay bit-identical and (almost) nothing is left
+    to the slow queue."""
+    rec, sp = small_scene(pkg, n=4096, grid=16, seed=40)
+    op = to_oracle_params(oracle, sp)
+    P = oracle.substep(rec, op, steps=2)
+    P["pos"][:, :3] *= np.float32(scale)
+    f = make_engine(pkg, P, sp, 0, debug=8)
+    f.DispatchN(3)
+    c = f.debug_counters()
+    assert_records_equal(f.download(), oracle.substep(P, op, steps=3), f"scale {scale}")
+    print(f"scale {scale}: slices/tile {c['slices'] / c['tiles']:.2f} groups/waveround {c['scangroups'] / max(c['waverounds'], 1):.1f} "
+          f"slow {c['slow_lanes']} overflow slices {c['overflow_slices']} targets {c['targets']}")
+    assert c["scangroups"] / max(c["waverounds"], 1) > 12          # the chunked path really ran
+    if scale >= 0.6:
+        assert c["slow_lanes"] == 0 and c["overflow_slices"] == 0
+    f.close()
+
+
+def test_linked_list_variant_within_tolerance(pkg, oracle):
+    """SPH_OPT_GRID_BUILD = 1: the reference's own cellHead / particleNext scheme (A/B variant of
+    BASELINE.json configs[1]).  List order = atomic arrival order, so sums are not reproducible:
+    tolerance instead of bit equality (fp32, 1e-5 relative after 1 substep, 1e-3 after 10)."""
+    rec, sp = small_scene(pkg, n=4096, grid=16, seed=43)
+    op = to_oracle_params(oracle, sp)
+    P = oracle.substep(rec, op, steps=3)
+    f = make_engine(pkg, P, sp)
+    f.set_option(pkg.SPH_OPT_GRID_BUILD, 1)
+    f.DispatchCompute()
+    got, want = f.download(), oracle.substep(P, op)
+    err = np.abs(got["density"] - want["density"]) / want["density"]
+    assert err.max() < 1e-5, err.max()
+    # pressure = k (rho - rho0) amplifies the density error by k: absolute bound
+    assert np.abs(got["pressure"] - want["pressure"]).max() <= sp.param_gasConstant * 1e-5 * want["density"].max()
+    assert np.abs(got["pos"] - want["pos"]).max() < 1e-5 and np.abs(got["vel"] - want["vel"]).max() < 1e-2
+    for name in ("padB", "isGhost", "isActive", "padC", "pad0"):
+        assert np.array_equal(got[name], want[name])
+    f.DispatchN(9)
+    got, want = f.download(), oracle.substep(want, op, steps=9)
+    err = np.abs(got["density"] - want["density"]) / want["density"]
+    print("linked list, 10 substeps: max rel density err", err.max())
+    assert err.max() < 1e-3
+    # switching back to the counting sort mid-run keeps working (ids travel with the state)
+    f.set_option(pkg.SPH_OPT_GRID_BUILD, 0)
+    f.DispatchCompute()
+    assert np.isfinite(f.download()["pos"]).all()
+    f.close()
