@@ -483,8 +483,8 @@ int sph_set_option(SphEngine* e, int option, int value) {
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
     case SPH_OPT_DEBUG: e->tile.debugFlags = value; break;
     case SPH_OPT_TILE_CONFIG:
-        if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value");
-        e->tile.config = value; e->tile.tx = 8; e->tile.ty = 4; e->tile.tz = (value == 1) ? 3 : 4;
+        if (value < 0 || value > 4) return fail(SPH_ERR_ARG, "bad value");
+        e->tile.config = value; e->tile.tx = 8; e->tile.ty = (value == 4) ? 2 : 4; e->tile.tz = (value == 1) ? 3 : ((value >= 3) ? 2 : 4);
         break;
     case SPH_OPT_TILE_X: case SPH_OPT_TILE_Y: case SPH_OPT_TILE_Z: {
         int tx = e->tile.tx, ty = e->tile.ty, tz = e->tile.tz;
@@ -672,10 +672,8 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
     make_simk(e->params, e->grid, e->params.param_timeStep, k);
     HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 2 * sizeof(uint32_t), e->stream));
     uint32_t host[3] = {0, 0, 0};
-    // the live count of the previous dispatch bounds the slots that hold real data
-    HIP_TRY(hipMemcpyAsync(&host[2], e->d_slabCnt + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    e->nSlots = host[2];
+    // e->nSlots bounds the slots in use; the device-side live count (slabCnt[2]) trims it to the
+    // slots that hold data, so no host round trip is needed before the launch
     if (e->nSlots) {
         Timed t(e, SPH_K_OTHER);
         hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->nSlots)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
@@ -683,8 +681,9 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
                            (SlabRec*)sendLo, (SlabRec*)sendHi, capLo, capHi, e->d_slabCnt);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->nSlots = std::min<size_t>(e->nSlots, host[2]);
     if (host[0] > capLo || host[1] > capHi) return fail(SPH_ERR_CAPACITY, "halo send buffer too small (%u/%u lo, %u/%u hi)", host[0], capLo, host[1], capHi);
     countsOut[0] = host[0]; countsOut[1] = host[1];
     return SPH_OK;
@@ -703,9 +702,9 @@ int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* 
                                 e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], (int)e->nSlots);
     e->nSlots += nHi;
     HIP_TRY(hipGetLastError());
-    const uint32_t slots = (uint32_t)e->nSlots;   // until the next dispatch sorts again, every slot may hold data
-    HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, &slots, sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    // until the next dispatch sorts again, every slot may hold data
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt + 2, (uint32_t)e->nSlots);
+    HIP_TRY(hipGetLastError());
     return SPH_OK;
 }
 

@@ -500,10 +500,11 @@ __device__ __forceinline__ void slab_append(SlabRec* buf, uint32_t* counter, uin
 // counters[0] = records for the lower neighbour, counters[1] = for the upper neighbour.
 __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, int hasLo, int hasHi, float4* __restrict__ pos,
                                                       const float4* __restrict__ vel, const float2* __restrict__ rp,
-                                                      const float* __restrict__ foam, int n, SlabRec* __restrict__ sendLo,
+                                                      const float* __restrict__ foam, int nBound, SlabRec* __restrict__ sendLo,
                                                       SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi,
                                                       uint32_t* __restrict__ counters) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = min(nBound, (int)counters[2]);       // counters[2] = slots that hold data (live count of the last sort)
     bool toLoBuf = false, toHiBuf = false;
     SlabRec r;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = r.rho = r.prs = r.foam = 0.0f; r.id = 0; r.flags = 0; r.pad = 0;
@@ -549,6 +550,8 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
 }
+
+__global__ void k_set_u32(uint32_t* __restrict__ p, uint32_t v) { *p = v; }
 
 // Owned particles of a slab rank as 64-byte records (pos3, vel3, acc3, rho, P, foam, id, flags, 2 pad),
 // compacted; *count receives the number written.

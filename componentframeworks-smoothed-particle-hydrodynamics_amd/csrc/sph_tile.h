@@ -44,15 +44,18 @@ constexpr int kMaskBits = 96;        // candidates a per-thread mask can describ
 
 // LDS budget / workgroup shape of one build of the kernel.  160 KiB of LDS per CU: 53 KB
 // per workgroup -> 3 workgroups per CU, 40 KB -> 4, 32 KB -> 5.
-template <int THREADS, int MAXCAND, int POOL>
+template <int THREADS, int MAXCAND, int POOL, int MINWAVES = 1>
 struct TileCfg {
+    static constexpr int kMinWaves = MINWAVES; // __launch_bounds__ waves per SIMD the register allocator must allow
     static constexpr int kThreads = THREADS;   // multiple of 64
     static constexpr int kMaxCand = MAXCAND;   // staged particles per slice; slot kMaxCand is the sentinel
     static constexpr int kListPool = POOL;     // u16 entries shared by the slice's per-cell lists
 };
 using TileCfgA = TileCfg<256, 864, 128 * 88>;  // 52.8 KB: tile 8x4x4, 3 workgroups / CU
 using TileCfgB = TileCfg<256, 672, 96 * 72>;   // 38.0 KB: tile 8x4x3, 4 workgroups / CU
-using TileCfgC = TileCfg<320, 864, 128 * 88>;  // as A with 5 waves: one round for <= 320 targets
+using TileCfgD = TileCfg<192, 576, 64 * 104>;  // 34.6 KB: tile 8x4x2, 3 waves, 4 workgroups / CU
+using TileCfgE = TileCfg<128, 416, 32 * 104 + 1408>;  // 24.3 KB: tile 8x2x2, 2 waves, 6 workgroups / CU
+using TileCfgC = TileCfg<320, 864, 128 * 88, 4>;  // as A with 5 waves (one round for <= 320 targets); 15 waves / CU need <= 128 VGPRs
 
 template <class CFG>
 struct TileLdsT {
@@ -71,6 +74,7 @@ struct TileLdsT {
     uint16_t clSelf[kMaxCells];      // list position of the cell's own first particle
     int sliceTz;
     int maxLen;                      // longest 27-cell candidate list of the tile (slice planning)
+    int tileOver;                    // the whole tile (plus halo) exceeds kMaxCand
     static_assert((kMaxHaloCells + kMaxRows) * 4 <= kListPool * 2, "prologue cellStart copy must fit the list pool");
 };
 
@@ -78,7 +82,7 @@ struct TileLdsT {
 enum TileStamp {
     TS_PROLOGUE = 0, TS_STAGE, TS_LISTS, TS_SCAN, TS_SWEEP2, TS_SWEEP3, TS_EPILOGUE, TS_TOTAL,   // cycles
     TS_TILES, TS_SLICES, TS_WAVEROUNDS, TS_SCANGROUPS, TS_OVERFLOW_SLICES, TS_SLOW_LANES, TS_TARGETS, TS_CANDIDATES,
-    TS_WALK2MAX, TS_WALK2SUM, TS_RESCAN_LANES,
+    TS_WALK2MAX, TS_WALK2SUM, TS_RESCAN_LANES, TS_L_TGT, TS_L_BUILD,
     TS_COUNT
 };
 template <bool STAMP>
@@ -119,6 +123,11 @@ __device__ __forceinline__ int upper_row(const uint32_t* a, int n, uint32_t v) {
     }
     return lo;
 }
+
+// x / d for 0 <= x < 1024, 1 <= d <= 1024 without the ~35-instruction runtime integer division:
+// inv = floor(2^20 / d) + 1 is exact in that range (x * d < 2^20).
+__device__ __forceinline__ int fdiv_inv(int d) { return (int)((1u << 20) / (uint32_t)d) + 1; }
+__device__ __forceinline__ int fdiv(int x, int inv) { return (int)(((uint32_t)x * (uint32_t)inv) >> 20); }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -172,23 +181,25 @@ __device__ __forceinline__ void scan_chunk(const SimK& k, const LDS& L, Own& o, 
     }
 }
 
-// Visit the set bits of m2:m1:m0 from the top (= ascending candidate order); f(byteOffset).
-template <class F>
-__device__ __forceinline__ int walk_chunk(const uint16_t* clp, int g0, int g1, uint32_t m0, uint32_t m1, uint32_t m2, F&& f) {
+// Visit the set bits of m2:m1:m0 from the top (= ascending candidate order); f(pos4, vel4) per entry.
+template <class LDS, class F>
+__device__ __forceinline__ int walk_chunk(const LDS& L, const uint16_t* clp, int g0, int g1, uint32_t m0, uint32_t m1, uint32_t m2, F&& f) {
     const uint32_t topBit = (uint32_t)(8 * (g1 - g0) - 1);
     const uint16_t* cp = clp + 8 * g0;
     int trips = 0;
     while (m2) {
         const int p = 31 - __clz((int)m2);
         m2 &= ~(1u << p);
-        f((uint32_t)cp[topBit - (64u + (uint32_t)p)]);
+        const uint32_t off = cp[topBit - (64u + (uint32_t)p)];
+        f(lds_f4(L.pos, off), lds_f4(L.vel, off));
         ++trips;
     }
     uint64_t mm = ((uint64_t)m1 << 32) | (uint64_t)m0;
     while (mm) {
         const int p = 63 - __clzll((long long)mm);
         mm &= ~(1ull << p);
-        f((uint32_t)cp[topBit - (uint32_t)p]);
+        const uint32_t off = cp[topBit - (uint32_t)p];
+        f(lds_f4(L.pos, off), lds_f4(L.vel, off));
         ++trips;
     }
     return trips;
@@ -238,6 +249,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
     const int x0 = G.x0, y0 = G.y0, z0 = G.z0, tx = G.tx, ty = G.ty, tz = G.tz;
     const int HX = tx + 2, HY = ty + 2, HZ = tz + 2;
     const int R = HY * HZ;
+    const int iHX = fdiv_inv(HX), iHY = fdiv_inv(HY), iTX = fdiv_inv(tx), iTY = fdiv_inv(ty);
     const int xlo = max(x0 - 1, 0), xhi = min(x0 + tx, k.gx - 1);      // staged x range (inclusive)
     unsigned long long c0 = stamp_now<STAMP>();
     const uint32_t* cs = reinterpret_cast<const uint32_t*>(L.cl);
@@ -245,7 +257,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
     // cellStart of halo cell (hx, r) of this slice, hx in [0, HX]; cells outside the grid
     // collapse onto the nearest in-grid boundary so that differences give 0 particles.
     auto cs_at = [&](int r, int hx) -> uint32_t {
-        const int hy = r % HY, hz = r / HY;
+        const int hz = fdiv(r, iHY), hy = r - hz * HY;
         if (csInLds) return cs[((G.csZ + hz) * G.csHY + G.csY + hy) * G.csW + G.csX + hx];
         const int yy = y0 - 1 + hy, zz = z0 - 1 + hz;
         if (yy < 0 || yy >= k.gy || zz < 0 || zz >= k.gz) return 0u;
@@ -271,7 +283,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         // ---- slice overflow: every target of this slice goes to the slow queue ----
         if (STAMP && tid == 0) stamp_add<STAMP>(st, TS_OVERFLOW_SLICES, 1);
         for (int ir = 0; ir < ty * tz; ++ir) {
-            const int iy = ir % ty, iz = ir / ty;
+            const int iz = fdiv(ir, iTY), iy = ir - iz * ty;
             const int yy = y0 + iy, zz = z0 + iz;
             if (yy >= k.gy || zz >= k.gz || x0 >= k.gx) continue;
             const int base = (zz * k.gy + yy) * k.gx;
@@ -285,7 +297,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
     // ---- 2. per-cell LDS offsets of the halo box ----
     const int nHalo = HX * R;
     for (int ci = tid; ci < nHalo; ci += kTileThreads) {
-        const int r = ci / HX, hx = ci - r * HX;
+        const int r = fdiv(ci, iHX), hx = ci - r * HX;
         L.cellOff[ci] = (uint16_t)(L.rowL[r] + (cs_at(r, hx) - L.rowG[r]));
     }
     if (tid == 0) { L.cellOff[nHalo] = (uint16_t)nC; L.cellOff[nHalo + 1] = (uint16_t)nC; }
@@ -332,7 +344,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
     if (tid < 64) {
         uint32_t cnt = 0;
         if (tid < IR) {
-            const int iy = tid % ty, iz = tid / ty;
+            const int iz = fdiv(tid, iTY), iy = tid - iz * ty;
             const int r = (iz + 1) * HY + (iy + 1);
             cnt = (uint32_t)L.cellOff[r * HX + 1 + tx] - (uint32_t)L.cellOff[r * HX + 1];
         }
@@ -340,6 +352,8 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         if (tid < IR) L.tgtStart[tid] = inc - cnt;
         if (tid == IR - 1) L.tgtStart[IR] = inc;
     }
+    const unsigned long long l0 = stamp_now<STAMP>();
+    if (STAMP && tid == 0) stamp_add<STAMP>(st, TS_L_TGT, l0 - c0);
     {   // Wave-cooperative list build.  A wave takes one interior (y,z) row of cells at a time;
         // lane = (cell of the row) * 8 + j copies entry j, j+8, ... of each of the 9 runs, then
         // pads the cell's list with the sentinel up to the stride.  No cross-lane traffic: the
@@ -352,7 +366,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         for (int c0 = wave * cpw; c0 < nCells; c0 += kWaves * cpw) {
             const int c = c0 + (lane >> 3);
             if (c >= nCells) continue;
-            const int ix = c % tx, iy = (c / tx) % ty, iz = c / (tx * ty);
+            const int cq = fdiv(c, iTX), ix = c - cq * tx, iz = fdiv(cq, iTY), iy = cq - iz * ty;
             const int off0 = (iz * HY + iy) * HX + ix;               // halo cell (hx-1, hy-1, hz-1)
             int qs[9], ln[9];
 #pragma unroll
@@ -364,22 +378,37 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
             const int mid = (int)L.cellOff[off0 + (HY + 1) * HX + 1] - qs[4];
             const int base = c * CLs;
             int pre = 0, selfK = 0;
+            uint16_t* dst = &L.cl[base];
 #pragma unroll
             for (int run = 0; run < 9; ++run) {
                 if (run == 4) selfK = pre + mid;
-                for (int e = j; e < ln[run]; e += 8) {
-                    const int p = pre + e;
-                    if (p < cap) L.cl[base + p] = (uint16_t)((qs[run] + e) * 16);
+                // entries j and j+8 of the run as straight-line predicated stores (runs of 3 cells
+                // rarely hold more than 16 particles); anything longer in a plain scalar loop
+                const int n = ln[run], q0 = qs[run];
+                if (j < n && pre + j < cap) dst[pre + j] = (uint16_t)((q0 + j) * 16);
+                if (j + 8 < n && pre + j + 8 < cap) dst[pre + j + 8] = (uint16_t)((q0 + j + 8) * 16);
+                if (n > 16) {
+#pragma clang loop vectorize(disable) unroll(disable)
+                    for (int e = j + 16; e < n; e += 8)
+                        if (pre + e < cap) dst[pre + e] = (uint16_t)((q0 + e) * 16);
                 }
-                pre += ln[run];
+                pre += n;
             }
-            for (int p = min(pre, cap) + j; p < CLs; p += 8) L.cl[base + p] = sent;
+            {   // sentinel padding up to the stride, one 16-B slot (8 entries) per lane where possible
+                const int p0 = min(pre, cap);
+                const int pa = (p0 + 7) & ~7;                        // first whole slot
+                if (p0 + j < pa) dst[p0 + j] = sent;                 // ragged head
+                const uint32_t sv = (uint32_t)sent * 0x10001u;
+#pragma clang loop vectorize(disable) unroll(disable)
+                for (int p = pa + 8 * j; p < CLs; p += 64) *reinterpret_cast<uint4*>(dst + p) = make_uint4(sv, sv, sv, sv);
+            }
             if (j == 0) {
                 L.clSelf[c] = (uint16_t)selfK;
                 L.clLen[c] = (pre <= cap && !(dbg & 1)) ? (uint16_t)pre : (uint16_t)0xFFFFu;
             }
         }
     }
+    if (STAMP && (tid & 63) == 0) stamp_add<STAMP>(st, TS_L_BUILD, stamp_now<STAMP>() - l0);
     __syncthreads();
     const uint32_t nT = L.tgtStart[IR];
     if (STAMP && tid == 0) { const unsigned long long c1 = stamp_now<STAMP>(); stamp_add<STAMP>(st, TS_LISTS, c1 - c0); c0 = c1; stamp_add<STAMP>(st, TS_TARGETS, nT); }
@@ -394,7 +423,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         const bool valid = (t0 + tid) < nT;
         const uint32_t t = valid ? (t0 + tid) : (nT - 1);
         const int ir = upper_row(L.tgtStart, IR + 1, t);
-        const int iy = ir % ty, iz = ir / ty;
+        const int iz = fdiv(ir, iTY), iy = ir - iz * ty;
         const int hy = iy + 1, hz = iz + 1;
         const int r = hz * HY + hy;
         const uint32_t li = (uint32_t)L.cellOff[r * HX + 1] + (t - L.tgtStart[ir]);
@@ -468,26 +497,24 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
                 a0 &= ~(w == 0 ? bit : 0u); a1 &= ~(w == 1 ? bit : 0u); a2 &= ~(w == 2 ? bit : 0u);
             }
         };
-        auto force_at = [&](uint32_t off) {
-            const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
+        auto force_at = [&](const float4& J, const float4& JV) {
             if (J.w > 0.0f) pair_force_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w);
         };
-        auto xsph_at = [&](uint32_t off) {
-            const float4 J = lds_f4(L.pos, off), JV = lds_f4(L.vel, off);
+        auto xsph_at = [&](const float4& J, const float4& JV) {
             if (J.w > 0.0f) pair_xsph_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w);
         };
         int trips2 = 0;
         // sweep 2: forces, ascending candidate order
         if (!dense) {
             drop_self(0, groups, m0, m1, m2);
-            trips2 = walk_chunk(clp, 0, groups, m0, m1, m2, force_at);
+            trips2 = walk_chunk(L, clp, 0, groups, m0, m1, m2, force_at);
         } else {
             for (int g0 = 0; g0 < groups; g0 += 12) {
                 const int g1 = min(g0 + 12, groups);
                 uint32_t t0, t1, t2;
                 scan_chunk<false>(k, L, o, clp, g0, g1, ex, ey, ez, k.h2hi, t0, t1, t2);
                 drop_self(g0, g1, t0, t1, t2);
-                trips2 += walk_chunk(clp, g0, g1, t0, t1, t2, force_at);
+                trips2 += walk_chunk(L, clp, g0, g1, t0, t1, t2, force_at);
             }
         }
         integrate(k, o);
@@ -500,7 +527,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
         const float lim = 0.98f * slack;
         const bool maskOk = !dense && (moved2 <= lim * lim) && !(dbg & 2);
         if (!__any(!maskOk)) {                                     // uniform over the lanes still active
-            (void)walk_chunk(clp, 0, groups, m0, m1, m2, xsph_at);
+            (void)walk_chunk(L, clp, 0, groups, m0, m1, m2, xsph_at);
         } else {
             if (STAMP && valid && !maskOk) stamp_add<STAMP>(st, TS_RESCAN_LANES, 1);
             for (int g0 = 0; g0 < groups; g0 += 12) {
@@ -508,7 +535,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
                 uint32_t t0, t1, t2;
                 scan_chunk<false>(k, L, o, clp, g0, g1, o.px, o.py, o.pz, k.h2, t0, t1, t2);
                 drop_self(g0, g1, t0, t1, t2);
-                (void)walk_chunk(clp, g0, g1, t0, t1, t2, xsph_at);
+                (void)walk_chunk(L, clp, g0, g1, t0, t1, t2, xsph_at);
             }
         }
         const unsigned long long w3 = stamp_now<STAMP>();
@@ -527,7 +554,7 @@ __device__ __forceinline__ void tile_slice(TileLdsT<CFG>& L, const SimK& k, int 
 }
 
 template <bool STAMP, class CFG>
-__global__ __launch_bounds__(CFG::kThreads) void k_sph_tile(SimK k, TileGeom g, StateIn in, StateOut out,
+__global__ __launch_bounds__(CFG::kThreads, CFG::kMinWaves) void k_sph_tile(SimK k, TileGeom g, StateIn in, StateOut out,
                                                             const uint32_t* __restrict__ order,
                                                             const uint32_t* __restrict__ cellStart, SlowQueue slowq,
                                                             unsigned long long* stAll) {
@@ -554,9 +581,10 @@ __global__ __launch_bounds__(CFG::kThreads) void k_sph_tile(SimK k, TileGeom g, 
     //      row's end) into LDS, aliased on the list pool ----
     uint32_t* cs = reinterpret_cast<uint32_t*>(L.cl);
     const int W = HX + 1;
+    const int iW = fdiv_inv(W), iHYt = fdiv_inv(HY), iTXt = fdiv_inv(g.tx), iTYt = fdiv_inv(g.ty);
     for (int ci = tid; ci < W * HY * HZ; ci += kTileThreads) {
-        const int r = ci / W, hx = ci - r * W;
-        const int hy = r % HY, hz = r / HY;
+        const int r = fdiv(ci, iW), hx = ci - r * W;
+        const int hz = fdiv(r, iHYt), hy = r - hz * HY;
         const int yy = y0 - 1 + hy, zz = z0 - 1 + hz;
         uint32_t v = 0;
         if (yy >= 0 && yy < k.gy && zz >= 0 && zz < k.gz) {
@@ -569,12 +597,18 @@ __global__ __launch_bounds__(CFG::kThreads) void k_sph_tile(SimK k, TileGeom g, 
         L.pos[kMaxCand] = make_float4(1e18f, 1e18f, 1e18f, 0.0f);   // sentinel: never within any radius
         L.vel[kMaxCand] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         L.maxLen = 0;
+        L.tileOver = 0;
     }
     __syncthreads();
+    if (tid < 64) {   // staged particles of the whole tile
+        const uint32_t cnt = (tid < HY * HZ) ? (cs[tid * W + HX] - cs[tid * W]) : 0u;
+        const uint32_t total = (uint32_t)__shfl((int)wave_incl_scan(cnt), 63, 64);
+        if (tid == 0 && total > (uint32_t)kMaxCand) L.tileOver = 1;
+    }
     {   // longest candidate list among the tile's cells (from the cellStart copy)
         int mx = 0;
         for (int c = tid; c < g.tx * g.ty * g.tz; c += kTileThreads) {
-            const int ix = c % g.tx, iy = (c / g.tx) % g.ty, iz = c / (g.tx * g.ty);
+            const int cq = fdiv(c, iTXt), ix = c - cq * g.tx, iz = fdiv(cq, iTYt), iy = cq - iz * g.ty;
             int len = 0;
             for (int dz = 0; dz < 3; ++dz)
                 for (int dy = 0; dy < 3; ++dy) {
@@ -594,10 +628,12 @@ __global__ __launch_bounds__(CFG::kThreads) void k_sph_tile(SimK k, TileGeom g, 
     {
         const int needStride = max(72, ((L.maxLen + 7) & ~7) + 16);
         const int maxCellsPerBox = max(1, min(kMaxCells, CFG::kListPool / needStride));
-        for (;;) {
+        const bool whole = !L.tileOver && (sx * sy * sz <= maxCellsPerBox);   // the common case: no further barrier
+        if (!whole) for (;;) {
             while (sx * sy * sz > maxCellsPerBox) {
                 if (sz > 1) sz = (sz + 1) >> 1; else if (sy > 1) sy = (sy + 1) >> 1; else if (sx > 1) sx = (sx + 1) >> 1; else break;
             }
+            __syncthreads();
             if (tid == 0) L.sliceTz = 0;
             __syncthreads();
             const int nbx = (g.tx + sx - 1) / sx, nby = (g.ty + sy - 1) / sy, nbz = (g.tz + sz - 1) / sz;
@@ -614,7 +650,6 @@ __global__ __launch_bounds__(CFG::kThreads) void k_sph_tile(SimK k, TileGeom g, 
             if (over) L.sliceTz = 1;                                   // benign race: any writer writes 1
             __syncthreads();
             const bool bad = L.sliceTz != 0;
-            __syncthreads();
             if (!bad) break;
             if (sz > 1) sz = (sz + 1) >> 1; else if (sy > 1) sy = (sy + 1) >> 1; else if (sx > 1) sx = (sx + 1) >> 1;
             else break;                                                // single cells still overflow: those go to the slow queue
@@ -666,6 +701,8 @@ inline int tile_launch(TilePlan& plan, hipStream_t stream, const SimK& k, const 
         if (stamp) hipLaunchKernelGGL((k_sph_tile<true, CFG>), dim3(per * 8), dim3(CFG::kThreads), 0, stream, k, g, in, out, order, cellStart, slowq, sp); \
         else hipLaunchKernelGGL((k_sph_tile<false, CFG>), dim3(per * 8), dim3(CFG::kThreads), 0, stream, k, g, in, out, order, cellStart, slowq, sp);
         if (plan.config == 1) { SPH_LAUNCH_TILE(TileCfgB) }
+        else if (plan.config == 3) { SPH_LAUNCH_TILE(TileCfgD) }
+        else if (plan.config == 4) { SPH_LAUNCH_TILE(TileCfgE) }
         else if (plan.config == 2) { SPH_LAUNCH_TILE(TileCfgC) }
         else { SPH_LAUNCH_TILE(TileCfgA) }
 #undef SPH_LAUNCH_TILE

@@ -72,7 +72,8 @@ ABI_SYMBOLS = (
     "sph_debug_counters", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
 )
 STAMP_NAMES = ("prologue", "stage", "lists", "scan", "sweep2", "sweep3", "epilogue", "total", "tiles", "slices", "waverounds",
-               "scangroups", "overflow_slices", "slow_lanes", "targets", "candidates", "walk2max", "walk2sum", "rescan_lanes")
+               "scangroups", "overflow_slices", "slow_lanes", "targets", "candidates", "walk2max", "walk2sum", "rescan_lanes",
+               "l_tgt", "l_build")
 
 
 class SphError(RuntimeError):

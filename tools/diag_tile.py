@@ -44,6 +44,8 @@ wave_cycles = c["scan"] + c["sweep2"] + c["sweep3"] + c["epilogue"]
 for k in ("scan", "sweep2", "sweep3", "epilogue"):
     out[f"wave_share_{k}"] = round(c[k] / wave_cycles, 4)
     out[f"cycles_{k}_per_waveround"] = round(c[k] / max(c["waverounds"], 1))
+out["cycles_lists_tgtstart_wave0"] = round(c["l_tgt"] / c["tiles"])
+out["cycles_lists_build_per_wave"] = round(c["l_build"] / c["tiles"] / 4)
 out["cycles_per_tile"] = round(wg / c["tiles"])
 out["tiles_per_step"] = c["tiles"] / n
 out["slices_per_tile"] = round(c["slices"] / c["tiles"], 3)
