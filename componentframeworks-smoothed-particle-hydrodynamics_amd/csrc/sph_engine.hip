@@ -84,6 +84,8 @@ struct SphEngine {
     // grid / sort scratch
     uint32_t *d_cellOf = nullptr, *d_slotOf = nullptr, *d_order = nullptr;
     uint32_t *d_slowSlots = nullptr, *d_slowCount = nullptr;   // exceptional targets of the tiled pass
+    float4* d_stencil = nullptr;            // SetStencilTargets points (binding 5 of StencilAttract.comp)
+    size_t stencilCount = 0;
     int32_t *d_llNext = nullptr, *d_llCell = nullptr, *d_llKey = nullptr;   // linked-list A/B variant (particleNext, particleCell, cellKey)
     uint2* d_tmp = nullptr;
     uint32_t *d_cellCount = nullptr, *d_cellStart = nullptr, *d_blockSums = nullptr;
@@ -351,6 +353,23 @@ int dispatch_one(SphEngine* e, float overrideDt) {
 
 }  // namespace
 
+namespace {
+using namespace sph;
+template <class K>
+int launch_impulse(SphEngine* e, const K& kk) {
+    int rc;
+    if ((rc = import_state(e))) return rc;
+    const size_t nw = e->slab ? e->nSlots : e->n;
+    if (nw) {
+        Timed t(e, SPH_K_IMPULSE);
+        hipLaunchKernelGGL((k_impulse<K>), dim3(blocks_for(nw)), dim3(kBlock), 0, e->stream, kk, e->d_pos[e->cur], e->d_vel[e->cur],
+                           (e->aosValid && !e->slab) ? e->d_aos : nullptr, e->idBase, (int)nw);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+}  // namespace
+
 // ======================================================================== C-ABI
 extern "C" {
 
@@ -439,6 +458,7 @@ int sph_destroy(SphEngine* e) {
     free_particle_buffers(e);
     free_grid_buffers(e);
     dev_free(e->d_dbg);
+    dev_free(e->d_stencil);
     dev_free(e->d_stamps);
     for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -546,6 +566,65 @@ int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, floa
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
+}
+
+// ---- per-frame impulses beyond WaveImpulse ------------------------
+
+int sph_apply_vortex_impulse(SphEngine* e, float tangentKick, float inwardKick) {     // SPHFluid3D.cpp:627-646
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (std::fabs(tangentKick) < 1e-6f && std::fabs(inwardKick) < 1e-6f) return SPH_OK;
+    float R[9], half[3];
+    sph::rotation_mat3(e->params.param_boxEulerDeg, R);
+    sph::effective_half(e->params, half);
+    VortexK kk;
+    kk.cx = e->params.param_boxCenter[0]; kk.cy = e->params.param_boxCenter[1]; kk.cz = e->params.param_boxCenter[2];
+    kk.ax = R[3]; kk.ay = R[4]; kk.az = R[5];                                         // local +Y = column 1
+    kk.tangent = tangentKick; kk.inward = inwardKick;
+    kk.e1 = 0.35f * std::fmax(std::fmax(half[0], half[2]), 1e-4f);
+    return launch_impulse(e, kk);
+}
+
+int sph_apply_attractor_impulse(SphEngine* e, const float point[3], float pullKick, float radius) {   // SPHFluid3D.cpp:650-664
+    if (!e || !point) return fail(SPH_ERR_ARG, "null argument");
+    if (std::fabs(pullKick) < 1e-6f) return SPH_OK;
+    AttractorK kk;
+    kk.px = point[0]; kk.py = point[1]; kk.pz = point[2];
+    kk.radius = std::fmax(radius, 0.1f);
+    kk.soften = std::fmax(0.15f * radius, 0.2f);
+    kk.pullSoft = pullKick * kk.soften;
+    kk.e0 = 0.6f * kk.radius;
+    return launch_impulse(e, kk);
+}
+
+int sph_set_stencil_targets(SphEngine* e, const float* points4, size_t count) {       // SPHFluid3D.cpp:684-693
+    if (!e || (!points4 && count)) return fail(SPH_ERR_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    dev_free(e->d_stencil);
+    e->stencilCount = 0;
+    if (!count) return SPH_OK;
+    int rc;
+    if ((rc = dev_alloc(&e->d_stencil, count))) return rc;
+    HIP_TRY(hipMemcpy(e->d_stencil, points4, count * sizeof(float4), hipMemcpyHostToDevice));
+    e->stencilCount = count;
+    return SPH_OK;
+}
+
+int sph_apply_stencil_attract(SphEngine* e, float pullKick, float dampKick) {         // SPHFluid3D.cpp:695-710
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (e->stencilCount == 0 || !e->d_stencil) return SPH_OK;
+    if (std::fabs(pullKick) < 1e-6f && dampKick < 1e-6f) return SPH_OK;
+    StencilK kk;
+    kk.targets = e->d_stencil; kk.nTargets = (uint32_t)e->stencilCount;
+    kk.pull = pullKick; kk.oneMinusDamp = 1.0f - std::fmin(dampKick, 0.5f);
+    return launch_impulse(e, kk);
+}
+
+int sph_apply_curl_flow(SphEngine* e, float kick, float scale, float time) {          // SPHFluid3D.cpp:668-681
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (std::fabs(kick) < 1e-6f) return SPH_OK;
+    CurlK kk;
+    kk.kick = kick; kk.scale = std::fmax(scale, 1e-3f); kk.time = time;
+    return launch_impulse(e, kk);
 }
 
 size_t sph_num_particles(const SphEngine* e) { return e ? e->n : 0; }

@@ -354,6 +354,116 @@ __global__ __launch_bounds__(kBlock) void k_wave_impulse(WaveK w, float4* __rest
     }
 }
 
+// ======================= per-frame impulse kernels ================
+// VortexImpulse / AttractorImpulse / StencilAttract / CurlFlow.comp: velocity kicks with no
+// neighbour access, applied between substeps (Scene0p.cpp:3479-3531).  Each functor returns the
+// new velocity of one non-ghost particle; k_impulse updates the internal state and, when it is
+// current, the public array.  Operation order matches the oracle (fma only inside dot3).
+__device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
+    const float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return (t * t) * (3.0f - 2.0f * t);
+}
+
+struct VortexK {                       // VortexImpulse.comp:25-30
+    float cx, cy, cz, ax, ay, az, tangent, inward, e1;
+    __device__ __forceinline__ bool apply(const float4& P, uint32_t, float& vx, float& vy, float& vz) const {
+        const float rx = P.x - cx, ry = P.y - cy, rz = P.z - cz;
+        const float d = dot3(rx, ry, rz, ax, ay, az);
+        const float qx = rx - ax * d, qy = ry - ay * d, qz = rz - az * d;
+        const float r = sqrtf(dot3(qx, qy, qz, qx, qy, qz));
+        if (r < 1e-4f) return false;
+        const float hx = qx / r, hy = qy / r, hz = qz / r;
+        const float tx = ay * hz - az * hy, ty = az * hx - ax * hz, tz = ax * hy - ay * hx;
+        const float fall = smoothstepf(0.0f, e1, r);
+        const float kt = tangent * fall, ki = inward * fall;
+        vx = vx + (tx * kt - hx * ki); vy = vy + (ty * kt - hy * ki); vz = vz + (tz * kt - hz * ki);
+        return true;
+    }
+};
+struct AttractorK {                    // AttractorImpulse.comp:23-27
+    float px, py, pz, pullSoft, soften, radius, e0;
+    __device__ __forceinline__ bool apply(const float4& P, uint32_t, float& vx, float& vy, float& vz) const {
+        const float rx = px - P.x, ry = py - P.y, rz = pz - P.z;
+        const float d = sqrtf(dot3(rx, ry, rz, rx, ry, rz));
+        if (d < 1e-5f) return false;
+        float pull = pullSoft / (d + soften);
+        pull = pull * (1.0f - smoothstepf(e0, radius, d));
+        vx = vx + (rx / d) * pull; vy = vy + (ry / d) * pull; vz = vz + (rz / d) * pull;
+        return true;
+    }
+};
+struct StencilK {                      // StencilAttract.comp:26-29
+    const float4* __restrict__ targets;
+    uint32_t nTargets;
+    float pull, oneMinusDamp;
+    __device__ __forceinline__ bool apply(const float4& P, uint32_t index, float& vx, float& vy, float& vz) const {
+        const float4 t = targets[index % nTargets];
+        vx = (vx + (t.x - P.x) * pull) * oneMinusDamp;
+        vy = (vy + (t.y - P.y) * pull) * oneMinusDamp;
+        vz = (vz + (t.z - P.z) * pull) * oneMinusDamp;
+        return true;
+    }
+};
+__device__ __forceinline__ float fractf(float x) { return x - floorf(x); }
+__device__ __forceinline__ float hash13(float x, float y, float z) {            // CurlFlow.comp:30-34
+    x = fractf(x * 0.1031f); y = fractf(y * 0.1031f); z = fractf(z * 0.1031f);
+    const float dd = dot3(x, y, z, z + 31.32f, y + 31.32f, x + 31.32f);
+    x = x + dd; y = y + dd; z = z + dd;
+    return fractf((x + y) * z);
+}
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float vnoise(float x, float y, float z) {            // CurlFlow.comp:36-50
+    const float ix = floorf(x), iy = floorf(y), iz = floorf(z);
+    float fx = x - ix, fy = y - iy, fz = z - iz;
+    fx = (fx * fx) * (3.0f - 2.0f * fx); fy = (fy * fy) * (3.0f - 2.0f * fy); fz = (fz * fz) * (3.0f - 2.0f * fz);
+    const float n000 = hash13(ix, iy, iz), n100 = hash13(ix + 1.0f, iy, iz);
+    const float n010 = hash13(ix, iy + 1.0f, iz), n110 = hash13(ix + 1.0f, iy + 1.0f, iz);
+    const float n001 = hash13(ix, iy, iz + 1.0f), n101 = hash13(ix + 1.0f, iy, iz + 1.0f);
+    const float n011 = hash13(ix, iy + 1.0f, iz + 1.0f), n111 = hash13(ix + 1.0f, iy + 1.0f, iz + 1.0f);
+    return mixf(mixf(mixf(n000, n100, fx), mixf(n010, n110, fx), fy), mixf(mixf(n001, n101, fx), mixf(n011, n111, fx), fy), fz);
+}
+__device__ __forceinline__ float pot1(float x, float y, float z) { return vnoise(x, y, z); }
+__device__ __forceinline__ float pot2(float x, float y, float z) { return vnoise(x + 31.416f, y + 47.853f, z + 12.793f); }
+__device__ __forceinline__ float pot3(float x, float y, float z) { return vnoise(x + -233.145f, y + 93.912f, z + 55.121f); }
+struct CurlK {                         // CurlFlow.comp:25-28
+    float kick, scale, time;
+    __device__ __forceinline__ bool apply(const float4& P, uint32_t, float& vx, float& vy, float& vz) const {
+        const float h = 0.35f;
+        const float qx = P.x * scale, qy = P.y * scale, qz = P.z * scale + time;
+        const float dP3dy = pot3(qx, qy + h, qz) - pot3(qx, qy - h, qz);
+        const float dP2dz = pot2(qx, qy, qz + h) - pot2(qx, qy, qz - h);
+        const float dP1dz = pot1(qx, qy, qz + h) - pot1(qx, qy, qz - h);
+        const float dP3dx = pot3(qx + h, qy, qz) - pot3(qx - h, qy, qz);
+        const float dP2dx = pot2(qx + h, qy, qz) - pot2(qx - h, qy, qz);
+        const float dP1dy = pot1(qx, qy + h, qz) - pot1(qx, qy - h, qz);
+        const float inv = 2.0f * h;
+        const float cx = (dP3dy - dP2dz) / inv, cy = (dP1dz - dP3dx) / inv, cz = (dP2dx - dP1dy) / inv;
+        const float m = sqrtf(dot3(cx, cy, cz, cx, cy, cz));
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (m > 1e-5f) { dx = cx / m; dy = cy / m; dz = cz / m; }
+        const float mm = fminf(m, 1.0f);
+        vx = vx + (dx * mm) * kick; vy = vy + (dy * mm) * kick; vz = vz + (dz * mm) * kick;
+        return true;
+    }
+};
+
+template <class K>
+__global__ __launch_bounds__(kBlock) void k_impulse(K kk, const float4* __restrict__ pos, float4* __restrict__ vel,
+                                                    SphParticle* __restrict__ aosOrNull, uint32_t idBase, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const float4 P = pos[s];
+    if (fbits(P.w) & (F_GHOSTNZ | F_DEAD)) return;             // `if (p.isGhost != 0) return;`
+    float4 V = vel[s];
+    const uint32_t index = fbits(V.w) - idBase;
+    if (!kk.apply(P, index, V.x, V.y, V.z)) return;
+    vel[s] = V;
+    if (aosOrNull) {
+        float* rec = reinterpret_cast<float*>(aosOrNull + index);
+        rec[4] = V.x; rec[5] = V.y; rec[6] = V.z;
+    }
+}
+
 // ---- test support: per-cell counts in the reference's cell indexing -------------------------
 __global__ __launch_bounds__(kBlock) void k_debug_cells(const uint32_t* __restrict__ cellStart, int32_t* __restrict__ cellCount, int numCells) {
     int c = blockIdx.x * kBlock + threadIdx.x;

@@ -69,7 +69,8 @@ ABI_SYMBOLS = (
     "sph_set_option", "sph_get_option", "sph_dispatch", "sph_dispatch_n", "sph_apply_wave_impulse",
     "sph_num_particles", "sph_grid_info", "sph_upload_particles", "sph_download_particles",
     "sph_device_particles", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
-    "sph_debug_counters", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
+    "sph_debug_counters", "sph_apply_vortex_impulse", "sph_apply_attractor_impulse", "sph_set_stencil_targets",
+    "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
 )
 STAMP_NAMES = ("prologue", "stage", "lists", "scan", "sweep2", "sweep3", "epilogue", "total", "tiles", "slices", "waverounds",
                "scangroups", "overflow_slices", "slow_lanes", "targets", "candidates", "walk2max", "walk2sum", "rescan_lanes",
@@ -137,6 +138,11 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_sync.argtypes = [vp]
     L.sph_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.sph_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_int]
+    L.sph_apply_vortex_impulse.argtypes = [vp, C.c_float, C.c_float]
+    L.sph_apply_attractor_impulse.argtypes = [vp, f3, C.c_float, C.c_float]
+    L.sph_set_stencil_targets.argtypes = [vp, vp, C.c_size_t]
+    L.sph_apply_stencil_attract.argtypes = [vp, C.c_float, C.c_float]
+    L.sph_apply_curl_flow.argtypes = [vp, C.c_float, C.c_float, C.c_float]
     L.sph_create_slab.argtypes = [C.POINTER(vp), vp, vp, C.c_size_t, pp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp]
     L.sph_slab_pack.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.sph_slab_unpack.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -269,6 +275,24 @@ class SPHFluidGPU:
 
     def ApplyWaveImpulse(self, amplitude, wavelength, phase, dir, yMin=-FLT_MAX, yMax=FLT_MAX):   # SPHFluid3D.cpp:604
         _check(self._L.sph_apply_wave_impulse(self._h, amplitude, wavelength, phase, _f3(dir), yMin, yMax))
+
+    def ApplyVortexImpulse(self, tangentKick, inwardKick):          # SPHFluid3D.cpp:627
+        _check(self._L.sph_set_params(self._h, C.byref(self._p)))   # reads param_boxCenter / EulerDeg / half
+        _check(self._L.sph_apply_vortex_impulse(self._h, tangentKick, inwardKick))
+
+    def ApplyAttractorImpulse(self, point, pullKick, radius):        # SPHFluid3D.cpp:650
+        _check(self._L.sph_apply_attractor_impulse(self._h, _f3(point), pullKick, radius))
+
+    def SetStencilTargets(self, points):                             # SPHFluid3D.cpp:684
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+        _check(self._L.sph_set_stencil_targets(self._h, pts.ctypes.data_as(C.c_void_p), len(pts)))
+        object.__setattr__(self, "stencilCount", len(pts))
+
+    def ApplyStencilAttract(self, pullKick, dampKick):               # SPHFluid3D.cpp:695
+        _check(self._L.sph_apply_stencil_attract(self._h, pullKick, dampKick))
+
+    def ApplyCurlFlow(self, kick, scale, time):                      # SPHFluid3D.cpp:668
+        _check(self._L.sph_apply_curl_flow(self._h, kick, scale, time))
 
     def EffectiveHalf(self):                                         # SPHFluid3D.h:127
         return effective_half(self._p)

@@ -76,6 +76,26 @@ public:
         const float d[3] = {dir.x, dir.y, dir.z};
         Check(sph_apply_wave_impulse(engine, amplitude, wavelength, phase, d, yMin, yMax), "sph_apply_wave_impulse");
     }
+    void ApplyVortexImpulse(float tangentKick, float inwardKick) {       // SPHFluid3D.cpp:627
+        SphParams p = ToParams();
+        if (Check(sph_set_params(engine, &p), "sph_set_params")) return;
+        Check(sph_apply_vortex_impulse(engine, tangentKick, inwardKick), "sph_apply_vortex_impulse");
+    }
+    void ApplyAttractorImpulse(const MATH::Vec3& point, float pullKick, float radius) {   // SPHFluid3D.cpp:650
+        const float q[3] = {point.x, point.y, point.z};
+        Check(sph_apply_attractor_impulse(engine, q, pullKick, radius), "sph_apply_attractor_impulse");
+    }
+    void ApplyCurlFlow(float kick, float scale, float time) {            // SPHFluid3D.cpp:668
+        Check(sph_apply_curl_flow(engine, kick, scale, time), "sph_apply_curl_flow");
+    }
+    void SetStencilTargets(const std::vector<MATH::Vec4>& points) {      // SPHFluid3D.cpp:684
+        stencilCount = int(points.size());
+        Check(sph_set_stencil_targets(engine, points.empty() ? nullptr : &points[0].x, points.size()), "sph_set_stencil_targets");
+    }
+    void ApplyStencilAttract(float pullKick, float dampKick) {           // SPHFluid3D.cpp:695
+        Check(sph_apply_stencil_attract(engine, pullKick, dampKick), "sph_apply_stencil_attract");
+    }
+    int stencilCount = 0;                                                // SPHFluid3D.h:55
     MATH::Vec3 EffectiveHalf() const {                                  // SPHFluid3D.h:127
         SphParams p = ToParams();
         float h[3];

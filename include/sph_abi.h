@@ -161,6 +161,17 @@ int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps);
 int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, float phase,
                            const float dir[3], float yMin, float yMax);
 
+/* SPHFluidGPU::ApplyVortexImpulse, SPHFluid3D.cpp:627-646 + shaders/VortexImpulse.comp (kicks pre-multiplied by dt). */
+int sph_apply_vortex_impulse(SphEngine* e, float tangentKick, float inwardKick);
+/* SPHFluidGPU::ApplyAttractorImpulse, SPHFluid3D.cpp:650-664 + shaders/AttractorImpulse.comp. */
+int sph_apply_attractor_impulse(SphEngine* e, const float point[3], float pullKick, float radius);
+/* SPHFluidGPU::SetStencilTargets, SPHFluid3D.cpp:684-693: `count` points of 4 floats (w unused). */
+int sph_set_stencil_targets(SphEngine* e, const float* points4, size_t count);
+/* SPHFluidGPU::ApplyStencilAttract, SPHFluid3D.cpp:695-710 + shaders/StencilAttract.comp (target = points[i % count]). */
+int sph_apply_stencil_attract(SphEngine* e, float pullKick, float dampKick);
+/* SPHFluidGPU::ApplyCurlFlow, SPHFluid3D.cpp:668-681 + shaders/CurlFlow.comp. */
+int sph_apply_curl_flow(SphEngine* e, float kick, float scale, float time);
+
 /* ---- data ------------------------------------------------------------------------ */
 size_t sph_num_particles(const SphEngine* e);            /* particles.size() / GetNumFluids() */
 int sph_grid_info(const SphEngine* e, SphGridInfo* out); /* gridSize*, numCells, gridMinV, cellSize */

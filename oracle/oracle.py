@@ -95,6 +95,10 @@ def lib() -> C.CDLL:
         L.sph_oracle_substep.argtypes = [vp, vp, C.c_int, pp, C.c_float]
         L.sph_oracle_wave_impulse.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float,
                                               C.POINTER(C.c_float), C.c_float, C.c_float]
+        L.sph_oracle_vortex_impulse.argtypes = [vp, C.c_int, pp, C.c_float, C.c_float]
+        L.sph_oracle_attractor_impulse.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float]
+        L.sph_oracle_stencil_attract.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float]
+        L.sph_oracle_curl_flow.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float]
         L.sph_oracle_spawn.argtypes = [pp, C.c_int, C.c_uint32, vp, C.POINTER(C.c_float)]
         L.sph_oracle_spawn.restype = C.c_int
         L.sph_oracle_shape_supported.argtypes = [C.c_int]
@@ -192,6 +196,31 @@ def substep(P: np.ndarray, p: OParams, dt: float = -1.0, steps: int = 1) -> np.n
 def wave_impulse(P, amplitude, wavelength, phase, direction, y_min=-3.4028235e38, y_max=3.4028235e38):
     out = P.copy()
     lib().sph_oracle_wave_impulse(_ptr(out), len(out), amplitude, wavelength, phase, f3(direction), y_min, y_max)
+    return out
+
+
+def vortex_impulse(P, p: OParams, tangent_kick, inward_kick):
+    out = P.copy()
+    lib().sph_oracle_vortex_impulse(_ptr(out), len(out), C.byref(p), tangent_kick, inward_kick)
+    return out
+
+
+def attractor_impulse(P, point, pull_kick, radius):
+    out = P.copy()
+    lib().sph_oracle_attractor_impulse(_ptr(out), len(out), f3(point), pull_kick, radius)
+    return out
+
+
+def stencil_attract(P, targets, pull_kick, damp_kick):
+    out = P.copy()
+    t = np.ascontiguousarray(targets, dtype=np.float32).reshape(-1, 4)
+    lib().sph_oracle_stencil_attract(_ptr(out), len(out), _ptr(t) if len(t) else None, len(t), pull_kick, damp_kick)
+    return out
+
+
+def curl_flow(P, kick, scale, time):
+    out = P.copy()
+    lib().sph_oracle_curl_flow(_ptr(out), len(out), kick, scale, time)
     return out
 
 

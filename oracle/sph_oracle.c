@@ -708,3 +708,132 @@ void sph_oracle_set_threads(int n) {
     (void)n;
 #endif
 }
+
+/* ====================================================================================
+ * Per-frame impulse kernels.  Map-shaped, no neighbours.
+ * Contraction policy as above: dot products are fma chains, everything else rounds
+ * separately.  mix(a,b,t) = a*(1-t) + b*t, smoothstep = t*t*(3-2t) with
+ * t = clamp((x-e0)/(e1-e0), 0, 1), fract(x) = x - floor(x) (GLSL definitions).
+ * ==================================================================================== */
+static inline float o_smoothstep(float e0, float e1, float x) {
+    float t = o_clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return (t * t) * (3.0f - 2.0f * t);
+}
+
+/* ApplyVortexImpulse (SPHFluid3D.cpp:627-646) + shaders/VortexImpulse.comp:32-49 */
+void sph_oracle_vortex_impulse(OParticle* P, int n, const OParams* prm, float tangentKick, float inwardKick) {
+    if (fabsf(tangentKick) < 1e-6f && fabsf(inwardKick) < 1e-6f) return;
+    float R[9], half[3];
+    o_rotation(prm->boxEulerDeg, R);
+    sph_oracle_effective_half(prm, half);
+    const float ax = R[3], ay = R[4], az = R[5];             /* local +Y in world */
+    const float radius = fmaxf(half[0], half[2]);
+    const float e1 = 0.35f * fmaxf(radius, 1e-4f);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* p = &P[i];
+        if (p->isGhost != 0) continue;
+        float rx = p->pos[0] - prm->boxCenter[0], ry = p->pos[1] - prm->boxCenter[1], rz = p->pos[2] - prm->boxCenter[2];
+        float d = o_dot3(rx, ry, rz, ax, ay, az);
+        float qx = rx - ax * d, qy = ry - ay * d, qz = rz - az * d;
+        float r = sqrtf(o_dot3(qx, qy, qz, qx, qy, qz));
+        if (r < 1e-4f) continue;
+        float hx = qx / r, hy = qy / r, hz = qz / r;
+        float tx = ay * hz - az * hy, ty = az * hx - ax * hz, tz = ax * hy - ay * hx;   /* cross(axis, rHat) */
+        float fall = o_smoothstep(0.0f, e1, r);
+        float kt = tangentKick * fall, ki = inwardKick * fall;
+        p->vel[0] = p->vel[0] + (tx * kt - hx * ki);
+        p->vel[1] = p->vel[1] + (ty * kt - hy * ki);
+        p->vel[2] = p->vel[2] + (tz * kt - hz * ki);
+    }
+}
+
+/* ApplyAttractorImpulse (SPHFluid3D.cpp:650-664) + shaders/AttractorImpulse.comp:29-45 */
+void sph_oracle_attractor_impulse(OParticle* P, int n, const float point[3], float pullKick, float radius) {
+    if (fabsf(pullKick) < 1e-6f) return;
+    const float uRadius = fmaxf(radius, 0.1f);
+    const float uSoften = fmaxf(0.15f * radius, 0.2f);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* p = &P[i];
+        if (p->isGhost != 0) continue;
+        float rx = point[0] - p->pos[0], ry = point[1] - p->pos[1], rz = point[2] - p->pos[2];
+        float d = sqrtf(o_dot3(rx, ry, rz, rx, ry, rz));
+        if (d < 1e-5f) continue;
+        float pull = (pullKick * uSoften) / (d + uSoften);
+        pull = pull * (1.0f - o_smoothstep(0.6f * uRadius, uRadius, d));
+        p->vel[0] = p->vel[0] + (rx / d) * pull;
+        p->vel[1] = p->vel[1] + (ry / d) * pull;
+        p->vel[2] = p->vel[2] + (rz / d) * pull;
+    }
+}
+
+/* ApplyStencilAttract (SPHFluid3D.cpp:695-710) + shaders/StencilAttract.comp:31-44.
+ * targets: nTargets x 4 floats (w unused), SetStencilTargets (:684-693). */
+void sph_oracle_stencil_attract(OParticle* P, int n, const float* targets, int nTargets, float pullKick, float dampKick) {
+    if (nTargets <= 0 || !targets) return;
+    if (fabsf(pullKick) < 1e-6f && dampKick < 1e-6f) return;
+    const float uDamp = fminf(dampKick, 0.5f);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* p = &P[i];
+        if (p->isGhost != 0) continue;
+        const float* t = targets + 4 * ((unsigned)i % (unsigned)nTargets);
+        for (int a = 0; a < 3; ++a) {
+            float d = t[a] - p->pos[a];
+            float v = p->vel[a] + d * pullKick;
+            p->vel[a] = v * (1.0f - uDamp);
+        }
+    }
+}
+
+static inline float o_fract(float x) { return x - floorf(x); }
+static float o_hash13(float x, float y, float z) {           /* CurlFlow.comp:30-34 */
+    x = o_fract(x * 0.1031f); y = o_fract(y * 0.1031f); z = o_fract(z * 0.1031f);
+    float dd = o_dot3(x, y, z, z + 31.32f, y + 31.32f, x + 31.32f);
+    x = x + dd; y = y + dd; z = z + dd;
+    return o_fract((x + y) * z);
+}
+static inline float o_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+static float o_vnoise(float x, float y, float z) {           /* CurlFlow.comp:36-50 */
+    float ix = floorf(x), iy = floorf(y), iz = floorf(z);
+    float fx = x - ix, fy = y - iy, fz = z - iz;
+    fx = (fx * fx) * (3.0f - 2.0f * fx); fy = (fy * fy) * (3.0f - 2.0f * fy); fz = (fz * fz) * (3.0f - 2.0f * fz);
+    float n000 = o_hash13(ix, iy, iz), n100 = o_hash13(ix + 1.0f, iy, iz);
+    float n010 = o_hash13(ix, iy + 1.0f, iz), n110 = o_hash13(ix + 1.0f, iy + 1.0f, iz);
+    float n001 = o_hash13(ix, iy, iz + 1.0f), n101 = o_hash13(ix + 1.0f, iy, iz + 1.0f);
+    float n011 = o_hash13(ix, iy + 1.0f, iz + 1.0f), n111 = o_hash13(ix + 1.0f, iy + 1.0f, iz + 1.0f);
+    return o_mix(o_mix(o_mix(n000, n100, fx), o_mix(n010, n110, fx), fy),
+                 o_mix(o_mix(n001, n101, fx), o_mix(n011, n111, fx), fy), fz);
+}
+static inline float o_p1(float x, float y, float z) { return o_vnoise(x, y, z); }
+static inline float o_p2(float x, float y, float z) { return o_vnoise(x + 31.416f, y + 47.853f, z + 12.793f); }
+static inline float o_p3(float x, float y, float z) { return o_vnoise(x + -233.145f, y + 93.912f, z + 55.121f); }
+
+/* ApplyCurlFlow (SPHFluid3D.cpp:668-681) + shaders/CurlFlow.comp:57-80 */
+void sph_oracle_curl_flow(OParticle* P, int n, float kick, float scale, float time) {
+    if (fabsf(kick) < 1e-6f) return;
+    const float uScale = fmaxf(scale, 1e-3f);
+    const float h = 0.35f;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* p = &P[i];
+        if (p->isGhost != 0) continue;
+        float qx = p->pos[0] * uScale, qy = p->pos[1] * uScale, qz = p->pos[2] * uScale + time;
+        float dP3dy = o_p3(qx, qy + h, qz) - o_p3(qx, qy - h, qz);
+        float dP2dz = o_p2(qx, qy, qz + h) - o_p2(qx, qy, qz - h);
+        float dP1dz = o_p1(qx, qy, qz + h) - o_p1(qx, qy, qz - h);
+        float dP3dx = o_p3(qx + h, qy, qz) - o_p3(qx - h, qy, qz);
+        float dP2dx = o_p2(qx + h, qy, qz) - o_p2(qx - h, qy, qz);
+        float dP1dy = o_p1(qx, qy + h, qz) - o_p1(qx, qy - h, qz);
+        const float inv = 2.0f * h;
+        float cx = (dP3dy - dP2dz) / inv, cy = (dP1dz - dP3dx) / inv, cz = (dP2dx - dP1dy) / inv;
+        float m = sqrtf(o_dot3(cx, cy, cz, cx, cy, cz));
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (m > 1e-5f) { dx = cx / m; dy = cy / m; dz = cz / m; }
+        float mm = fminf(m, 1.0f);
+        p->vel[0] = p->vel[0] + (dx * mm) * kick;
+        p->vel[1] = p->vel[1] + (dy * mm) * kick;
+        p->vel[2] = p->vel[2] + (dz * mm) * kick;
+    }
+}
