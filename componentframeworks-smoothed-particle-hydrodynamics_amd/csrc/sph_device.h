@@ -31,6 +31,7 @@ struct SimK {
     float bcx, bcy, bcz, bhx, bhy, bhz, auxx, auxy, auxz;
     float negRest, oneMinusFric;
     int shape;
+    int obbDeferred;   // shape 7..14: the SPH pass skips OBB, k_obb_ext applies it afterwards
 };
 
 // flag bits packed into pos.w of the internal state
@@ -283,26 +284,36 @@ __device__ __forceinline__ bool shape_project(const SimK& k, float px, float py,
     }
 }
 
-// OBBConstraints.comp main() for one non-ghost particle: updates pos / vel in place.
-__device__ __forceinline__ void obb_apply(const SimK& k, float& px, float& py, float& pz, float& vx, float& vy, float& vz) {
+// worldToLocal :32-36
+__device__ __forceinline__ void obb_to_local(const SimK& k, float px, float py, float pz, float& lx, float& ly, float& lz) {
     float dx = px - k.bcx, dy = py - k.bcy, dz = pz - k.bcz;
-    float lx = dot3(dx, dy, dz, k.R[0], k.R[1], k.R[2]);      // worldToLocal :32-36
-    float ly = dot3(dx, dy, dz, k.R[3], k.R[4], k.R[5]);
-    float lz = dot3(dx, dy, dz, k.R[6], k.R[7], k.R[8]);
-    float qx, qy, qz, nx, ny, nz;
-    if (shape_project(k, lx, ly, lz, qx, qy, qz, nx, ny, nz)) {
-        float wx, wy, wz, tx, ty, tz;
-        matvec(k.R, nx, ny, nz, wx, wy, wz);                // :313
-        float len = sqrtf(dot3(wx, wy, wz, wx, wy, wz));
-        wx = wx / len; wy = wy / len; wz = wz / len;
-        matvec(k.R, qx, qy, qz, tx, ty, tz);                // :316
-        px = k.bcx + tx; py = k.bcy + ty; pz = k.bcz + tz;
-        float vn = dot3(vx, vy, vz, wx, wy, wz);            // :319-326
-        float nvx = vn * wx, nvy = vn * wy, nvz = vn * wz;
-        vx = k.negRest * nvx + k.oneMinusFric * (vx - nvx);
-        vy = k.negRest * nvy + k.oneMinusFric * (vy - nvy);
-        vz = k.negRest * nvz + k.oneMinusFric * (vz - nvz);
-    }
+    lx = dot3(dx, dy, dz, k.R[0], k.R[1], k.R[2]);
+    ly = dot3(dx, dy, dz, k.R[3], k.R[4], k.R[5]);
+    lz = dot3(dx, dy, dz, k.R[6], k.R[7], k.R[8]);
+}
+// Collision response :311-327 for a hit with local projected point q and local normal n.
+__device__ __forceinline__ void obb_respond(const SimK& k, float qx, float qy, float qz, float nx, float ny, float nz,
+                                            float& px, float& py, float& pz, float& vx, float& vy, float& vz) {
+    float wx, wy, wz, tx, ty, tz;
+    matvec(k.R, nx, ny, nz, wx, wy, wz);                // :313
+    float len = sqrtf(dot3(wx, wy, wz, wx, wy, wz));
+    wx = wx / len; wy = wy / len; wz = wz / len;
+    matvec(k.R, qx, qy, qz, tx, ty, tz);                // :316
+    px = k.bcx + tx; py = k.bcy + ty; pz = k.bcz + tz;
+    float vn = dot3(vx, vy, vz, wx, wy, wz);            // :319-326
+    float nvx = vn * wx, nvy = vn * wy, nvz = vn * wz;
+    vx = k.negRest * nvx + k.oneMinusFric * (vx - nvx);
+    vy = k.negRest * nvy + k.oneMinusFric * (vy - nvy);
+    vz = k.negRest * nvz + k.oneMinusFric * (vz - nvz);
+}
+
+// OBBConstraints.comp main() for one non-ghost particle: updates pos / vel in place.
+// Shapes 7..14 are applied by their own pass (sph_shapes_ext.h, k.obbDeferred).
+__device__ __forceinline__ void obb_apply(const SimK& k, float& px, float& py, float& pz, float& vx, float& vy, float& vz) {
+    if (k.obbDeferred) return;
+    float lx, ly, lz, qx, qy, qz, nx, ny, nz;
+    obb_to_local(k, px, py, pz, lx, ly, lz);
+    if (shape_project(k, lx, ly, lz, qx, qy, qz, nx, ny, nz)) obb_respond(k, qx, qy, qz, nx, ny, nz, px, py, pz, vx, vy, vz);
 }
 
 // Fully specified fp32 sine shared with the parity oracle's definition

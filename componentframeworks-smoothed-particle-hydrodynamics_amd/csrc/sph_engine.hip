@@ -97,6 +97,9 @@ struct SphEngine {
     bool slab = false;
     int z0 = 0, z1 = 0, hasLo = 0, hasHi = 0;
     size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count
+    float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
+    float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
+    sph::ShapeTab shapeTab{};
     uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count
     // tile scheduler scratch (sph_tile.h)
     sph::TilePlan tile{};
@@ -155,7 +158,7 @@ void free_particle_buffers(SphEngine* e) {
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
-    dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt);
+    dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt); dev_free(e->d_shapeTab);
     dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
     e->cap = 0;
 }
@@ -208,8 +211,6 @@ int ensure_grid_buffers(SphEngine* e) {
 
 int validate_params(const SphParams& p) {
     if (!(p.param_h > 0.0f)) return fail(SPH_ERR_ARG, "param_h must be > 0");
-    if (p.param_shapeType >= 7 && p.param_shapeType <= 14)
-        return fail(SPH_ERR_ARG, "param_shapeType %d (OBBConstraints.comp:144-296) is not implemented yet", p.param_shapeType);
     return SPH_OK;
 }
 
@@ -278,6 +279,28 @@ int writeback(SphEngine* e) {
     return SPH_OK;
 }
 
+// Table of the sampled-curve shapes for k_obb_ext, re-uploaded only when its inputs change.
+int ensure_shape_table(SphEngine* e) {
+    const SphParams& p = e->params;
+    const float key[8] = {(float)p.param_shapeType, p.param_boxHalf[0], p.param_boxHalf[1], p.param_boxHalf[2],
+                          p.param_shapeAux[0], p.param_shapeAux[1], p.param_shapeAux[2], 1.0f};
+    if (e->d_shapeTab && std::memcmp(key, e->shapeKey, sizeof(key)) == 0) return SPH_OK;
+    int rc;
+    if (!e->d_shapeTab && (rc = dev_alloc(&e->d_shapeTab, 128))) return rc;
+    float pts[384], b0[3];
+    const int cnt = shape_table(p, pts, b0);
+    float4 host[128];
+    for (int i = 0; i < cnt; ++i) host[i] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.0f);
+    if (cnt) {
+        // rare (parameter change): a synchronous copy keeps the pageable staging array safe
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpy(e->d_shapeTab, host, sizeof(float4) * (size_t)cnt, hipMemcpyHostToDevice));
+    }
+    e->shapeTab = sph::ShapeTab{e->d_shapeTab, cnt, b0[0], b0[1], b0[2]};
+    std::memcpy(e->shapeKey, key, sizeof(key));
+    return SPH_OK;
+}
+
 int dispatch_one(SphEngine* e, float overrideDt) {
     if (e->params.param_pause) return SPH_OK;                               // SPHFluid3D.cpp:432
     int rc;
@@ -295,7 +318,9 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     const int n = (int)(e->slab ? e->nSlots : e->n);
     StateIn in{e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur]};
     const int nx = e->cur ^ 1;
-    const bool fuseAos = !e->slab && e->optAos == 0 && e->aosValid;   // the array is current: keep it current from the SPH pass
+    if (k.obbDeferred && (rc = ensure_shape_table(e))) return rc;
+    // the array is current: keep it current from the SPH pass (not when OBB runs as its own pass afterwards)
+    const bool fuseAos = !e->slab && e->optAos == 0 && e->aosValid && !k.obbDeferred;
     StateOut out{e->d_pos[nx], e->d_vel[nx], e->d_rp[nx], e->d_foam[nx], e->d_acc, fuseAos ? e->d_aos : nullptr, e->idBase};
     if (e->optGridBuild == 1) {
         // ---- A/B variant: the reference's atomicExchange linked lists (no sorting) ----
@@ -338,6 +363,11 @@ int dispatch_one(SphEngine* e, float overrideDt) {
             }
         }
     }
+    }
+    if (n && k.obbDeferred) {                                               // :495-509 for shapes 7..14
+        Timed t(e, SPH_K_OTHER);
+        const uint32_t* live = (e->slab && e->optGridBuild != 1) ? e->d_cellStart + k.numCells : nullptr;
+        hipLaunchKernelGGL(k_obb_ext, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->shapeTab, out.pos, out.vel, live, n);
     }
     HIP_TRY(hipGetLastError());
     e->cur = nx;

@@ -122,6 +122,7 @@ inline void make_simk(const SphParams& p, const SphGridInfo& g, float dt, SimK& 
     k.negRest = -p.param_wallRestitution;
     k.oneMinusFric = 1.0f - p.param_wallFriction;
     k.shape = p.param_shapeType;
+    k.obbDeferred = (k.shape >= 7 && k.shape <= 14) ? 1 : 0;
 }
 
 // ---- spawn -------------------------------------------------------------------------
@@ -139,7 +140,58 @@ struct Pcg32 {
     float uniform(float lo, float hi) { return lo + (float(next() >> 8) * (1.0f / 16777216.0f)) * (hi - lo); }
 };
 
-// insideShape lambda of SPHFluid3D.cpp:167-289 for the shapes the engine implements.
+// Sampled curves of container shapes 9 / 11 / 12 / 14: the shader evaluates them at fixed
+// parameter values for every particle (OBBConstraints.comp:188-191, :232-236, :248-252,
+// :288-290); here they are tabulated once per dispatch.  out: 3 floats per point, at most 128
+// points; best0: the shader's initial nearest point.  Returns the point count.
+inline int shape_table(const SphParams& p, float* out, float best0[3]) {
+    const float hx = p.param_boxHalf[0], hy = p.param_boxHalf[1];
+    int n = 0;
+    best0[0] = best0[1] = best0[2] = 0.0f;
+    switch (p.param_shapeType) {
+    case 9: {
+        const float S = hx;
+        best0[0] = 3.0f * S;
+        for (int k = 0; k < 48; ++k, ++n) {
+            const float t = 6.2831853f * float(k) / 48.0f;
+            out[3 * n + 0] = S * (sinf(t) + 2.0f * sinf(2.0f * t));
+            out[3 * n + 1] = S * (0.35f * (-sinf(3.0f * t)));
+            out[3 * n + 2] = S * (cosf(t) - 2.0f * cosf(2.0f * t));
+        }
+        break;
+    }
+    case 11: case 14: {
+        const float R = hx, r = hy;
+        const float turns = std::fmax(1.0f, p.param_shapeAux[0]), H = std::fmax(p.param_shapeAux[1], r);
+        best0[0] = R; best0[1] = -H;
+        for (int k = 0; k < 64; ++k) {
+            const float f = float(k) / 63.0f;
+            const float t = f * turns * 6.2831853f;
+            const float y = (f - 0.5f) * 2.0f * H;
+            out[3 * n + 0] = R * cosf(t); out[3 * n + 1] = y; out[3 * n + 2] = R * sinf(t); ++n;
+            if (p.param_shapeType == 11) {
+                out[3 * n + 0] = R * cosf(t + 3.14159265f); out[3 * n + 1] = y; out[3 * n + 2] = R * sinf(t + 3.14159265f); ++n;
+            }
+        }
+        break;
+    }
+    case 12: {
+        const float S = hx * 0.0625f;
+        for (int k = 0; k < 64; ++k, ++n) {
+            const float t = 6.2831853f * float(k) / 64.0f;
+            const float st = sinf(t);
+            const float hxx = 16.0f * st * st * st;
+            const float hyy = 13.0f * cosf(t) - 5.0f * cosf(2.0f * t) - 2.0f * cosf(3.0f * t) - cosf(4.0f * t);
+            out[3 * n + 0] = S * hxx; out[3 * n + 1] = S * hyy; out[3 * n + 2] = 0.0f;
+        }
+        break;
+    }
+    default: break;
+    }
+    return n;
+}
+
+// insideShape lambda of SPHFluid3D.cpp:167-289.
 inline bool inside_shape(const SphParams& p, const float hf[3], float margin, float lx, float ly, float lz) {
     const float bx = p.param_boxHalf[0], by = p.param_boxHalf[1], bz = p.param_boxHalf[2];
     switch (p.param_shapeType) {
@@ -156,6 +208,42 @@ inline bool inside_shape(const SphParams& p, const float hf[3], float margin, fl
     case 6: { const float a = std::fmax(bx - margin, 1e-4f), b = std::fmax(by - margin, 1e-4f);
               const float u = lx / a, v = ly / b, w = lz / a;
               return (u * u + v * v + w * w) <= 1.0f; }
+    case 7: { const float pts = std::fmax(3.0f, p.param_shapeAux[0]), depth = std::fmin(std::fmax(p.param_shapeAux[1], 0.0f), 0.9f);
+              if (std::fabs(ly) > by - margin) return false;
+              const float ang = atan2f(lz, lx);
+              const float rMax = bx * (1.0f - depth * (0.5f + 0.5f * cosf(pts * ang))) - margin;
+              return rMax > 0.0f && (lx * lx + lz * lz) <= rMax * rMax; }
+    case 8: { const float a = std::fmax(bx - margin, 1e-4f), b = std::fmax(by - margin, 1e-4f);
+              const float n = std::fmin(std::fmax(p.param_shapeAux[2], 0.6f), 8.0f);
+              const float F = powf(std::fabs(lx) / a, n) + powf(std::fabs(ly) / b, n) + powf(std::fabs(lz) / a, n);
+              return F <= 1.0f; }
+    case 9: case 11: case 12: case 14: {
+              const float r = by - margin;
+              if (r <= 0.0f) return false;
+              float tab[384], b0[3];
+              const int cnt = shape_table(p, tab, b0);
+              float bestD2 = 1e30f;
+              for (int k = 0; k < cnt; ++k) {
+                  const float dx = lx - tab[3 * k], dy = ly - tab[3 * k + 1], dz = lz - tab[3 * k + 2];
+                  bestD2 = std::fmin(bestD2, dx * dx + dy * dy + dz * dz);
+              }
+              return bestD2 <= r * r; }
+    case 10: { const float wHalf = by - margin, tHalf = std::fmax(p.param_shapeAux[0], 0.05f) - margin;
+              if (wHalf <= 0.0f || tHalf <= 0.0f) return false;
+              const float phi = atan2f(lz, lx);
+              const float erx = cosf(phi), erz = sinf(phi);
+              const float ox = lx - bx * erx, oy = ly, oz = lz - bx * erz;
+              const float psi = 0.5f * phi;
+              const float cw = cosf(psi), sw = sinf(psi);
+              const float du = ox * (cw * erx) + oy * (sw) + oz * (cw * erz);
+              const float dv = ox * (-sw * erx) + oy * (cw) + oz * (-sw * erz);
+              return std::fabs(du) <= wHalf && std::fabs(dv) <= tHalf; }
+    case 13: { const float R = bx - margin;
+              const float sc = std::fmax(p.param_shapeAux[0], 0.1f), th = std::fmin(std::fmax(p.param_shapeAux[1], 0.2f), 2.5f);
+              if (lx * lx + ly * ly + lz * lz > R * R) return false;
+              const float qx = lx * sc, qy = ly * sc, qz = lz * sc;
+              const float g = sinf(qx) * cosf(qy) + sinf(qy) * cosf(qz) + sinf(qz) * cosf(qx);
+              return std::fabs(g) <= th; }
     default: return true;
     }
 }

@@ -23,6 +23,9 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
+}  // namespace sph
+#include "sph_shapes_ext.h"
+namespace sph {
 
 // ---- AoS -> internal state (after upload / reset) ------------------------------------
 __global__ __launch_bounds__(kBlock) void k_import(const SphParticle* __restrict__ aos, float4* __restrict__ pos,
@@ -243,6 +246,20 @@ __device__ __forceinline__ void store_particle(const SimK& k, const StateOut& ou
     out.foam[s] = foamOut;
     if (out.aos) aos_write_fluid(out.aos, id - out.idBase, o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
     else out.acc[s] = make_float4(o.ax, o.ay, o.az, 0.0f);
+}
+
+// OBBConstraints.comp for container shapes 7..14, applied to the SPH pass's output state
+// (slot order).  liveCount (nullable) bounds the slots that hold particles in slab mode.
+__global__ __launch_bounds__(kBlock) void k_obb_ext(SimK k, ShapeTab T, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                    const uint32_t* __restrict__ liveCount, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const int bound = liveCount ? min(n, (int)*liveCount) : n;
+    if (s >= bound) return;
+    float4 P = pos[s];
+    if (fbits(P.w) & (F_GHOSTNZ | F_HALO)) return;          // OBBConstraints.comp:46; halo copies are never targets
+    float4 V = vel[s];
+    obb_apply_ext(k, T, P.x, P.y, P.z, V.x, V.y, V.z);
+    pos[s] = P; vel[s] = V;
 }
 
 // SPHFluid.comp main() for the particle in sorted slot s, neighbours gathered from global

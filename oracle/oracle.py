@@ -86,6 +86,14 @@ def lib() -> C.CDLL:
         L.sph_oracle_default_params.argtypes = [pp]
         L.sph_oracle_sinf.argtypes = [C.c_float]
         L.sph_oracle_sinf.restype = C.c_float
+        L.sph_oracle_cosf.argtypes = [C.c_float]
+        L.sph_oracle_cosf.restype = C.c_float
+        L.sph_oracle_atan2f.argtypes = [C.c_float, C.c_float]
+        L.sph_oracle_atan2f.restype = C.c_float
+        L.sph_oracle_powf.argtypes = [C.c_float, C.c_float]
+        L.sph_oracle_powf.restype = C.c_float
+        L.sph_oracle_shape_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sph_oracle_shape_table.restype = C.c_int
         L.sph_oracle_rotation.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.sph_oracle_effective_half.argtypes = [pp, C.POINTER(C.c_float)]
         L.sph_oracle_grid_extents.argtypes = [pp, C.POINTER(OGrid)]
@@ -234,6 +242,26 @@ def spawn(p: OParams, n_requested: int, seed: int):
 
 def sinf(x: float) -> float:
     return float(lib().sph_oracle_sinf(float(x)))
+
+
+def cosf(x: float) -> float:
+    return float(lib().sph_oracle_cosf(float(x)))
+
+
+def atan2f(y: float, x: float) -> float:
+    return float(lib().sph_oracle_atan2f(float(y), float(x)))
+
+
+def powf(x: float, p: float) -> float:
+    return float(lib().sph_oracle_powf(float(x), float(p)))
+
+
+def shape_table(params):
+    """Sampled curve of container shapes 9 / 11 / 12 / 14: (points[k,3], best0[3])."""
+    tab = np.zeros((128, 3), np.float32)
+    b0 = np.zeros(3, np.float32)
+    n = lib().sph_oracle_shape_table(C.byref(params), tab.ctypes.data_as(C.c_void_p), b0.ctypes.data_as(C.c_void_p))
+    return tab[:n].copy(), b0
 
 
 def set_threads(n: int):

@@ -50,6 +50,13 @@
  *     neighbour: invRho_j = 1/rho_j gives `mass / pj.density` (SPHFluid.comp:141,147,192)
  *     = mass * invRho_j and `x / (2.0 * pj.density)` (:137) = (x * 0.5) * invRho_j; and
  *     `rij / r` (:54) = rij * (1/r).  Every other division is written as in the shader.
+ * 10. cos, atan(y,x) and pow of OBBConstraints.comp:144-296 (container shapes 7..14) are, like
+ *     sin (5), fully specified fp32 routines: the sine's Cody-Waite reduction shifted by a
+ *     quadrant; cephes atanf with a fixed operation order; pow(x,p) = exp2(p*log2 x) with an
+ *     fdlibm-style log and a degree-6 exp2 polynomial (|rel. error| <= about 6e-8 * (1 + |p log2 x|)).
+ *     The curves those shapes sample at fixed parameter values (trefoil, DNA, heart, coil) are
+ *     tabulated once per dispatch with the host's libm; the spawn's insideShape is host code in
+ *     the reference too and uses libm.
  */
 #include <math.h>
 #include <stdint.h>
@@ -412,16 +419,267 @@ typedef struct {
     float c[3], half[3], aux[3];
     float e, f;
     int shape;
+    float tab[384];                                          /* sampled curve of shapes 9/11/12/14 */
+    int tabCount;
+    float best0[3];
 } OObb;
+
+int sph_oracle_shape_table(const OParams* p, float* out, float best0[3]);
+
 
 static void o_obb_setup(const OParams* p, OObb* b) {
     o_rotation(p->boxEulerDeg, b->R);                        /* SPHFluid3D.cpp:498-506 */
     for (int a = 0; a < 3; ++a) { b->c[a] = p->boxCenter[a]; b->half[a] = p->boxHalf[a]; b->aux[a] = p->shapeAux[a]; }
     b->e = p->wallRestitution; b->f = p->wallFriction; b->shape = p->shapeType;
+    b->tabCount = sph_oracle_shape_table(p, b->tab, b->best0);
 }
 
 static inline void o_matvec(const float R[9], const float v[3], float out[3]) {
     for (int i = 0; i < 3; ++i) out[i] = fmaf(R[6 + i], v[2], fmaf(R[3 + i], v[1], R[i] * v[0]));
+}
+
+
+/* ====================================================================================
+ * Container shapes 7..14 (OBBConstraints.comp:144-296) and the matching insideShape
+ * cases of the spawn (SPHFluid3D.cpp:200-289).
+ *
+ * Semantic 10: the shader's cos / atan(y,x) / pow are fixed as fully specified fp32
+ * routines (o_cosf, o_atan2f, o_powf), like o_sinf, so that the HIP kernels can match
+ * bit for bit.  Curves that the shader samples at FIXED parameter values (trefoil, DNA,
+ * heart, coil) are tabulated once per dispatch on the host with libm and handed to the
+ * kernel; the oracle builds the identical table (o_shape_table).
+ * ==================================================================================== */
+float sph_oracle_cosf(float x) {
+    const float TWO_OVER_PI = 0.636619772367581343f;
+    const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.549789948768648e-8f;
+    float q = rintf(x * TWO_OVER_PI);
+    float r = fmaf(q, -P1, x);
+    r = fmaf(q, -P2, r);
+    r = fmaf(q, -P3, r);
+    int n = ((int)(q - 4.0f * floorf(q * 0.25f)) + 1) & 3;      /* cos x = sin(x + pi/2) */
+    float r2 = r * r, res;
+    if (n & 1) {
+        float c = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+        c = fmaf(c, r2, 4.166664568298827e-2f);
+        c = fmaf(c, r2, -0.5f);
+        res = fmaf(c, r2, 1.0f);
+    } else {
+        float s = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+        s = fmaf(s, r2, -1.6666654611e-1f);
+        s = s * r2;
+        res = fmaf(s, r, r);
+    }
+    return (n & 2) ? -res : res;
+}
+
+static float o_atanf(float x) {                              /* cephes atanf, fixed op order */
+    float sign = 1.0f;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    y = y + fmaf(p * z, x, x);
+    return sign * y;
+}
+float sph_oracle_atan2f(float y, float x) {                  /* GLSL atan(y, x) */
+    const float PI = 3.14159265358979323846f, PIO2 = 1.5707963267948966f;
+    if (x > 0.0f) return o_atanf(y / x);
+    if (x < 0.0f) return (y >= 0.0f) ? (o_atanf(y / x) + PI) : (o_atanf(y / x) - PI);
+    return (y > 0.0f) ? PIO2 : ((y < 0.0f) ? -PIO2 : 0.0f);
+}
+
+static inline uint32_t o_fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float o_bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static float o_log2f(float x) {                              /* x > 0, normal; fdlibm-style, fixed op order */
+    uint32_t ix = o_fbits(x);
+    int e = (int)((int32_t)(ix - 0x3f3504f3u) >> 23);        /* floor(log2(x / sqrt(1/2))) */
+    ix = ix - ((uint32_t)e << 23);
+    float m = o_bitsf(ix);                                   /* in [sqrt(1/2), sqrt(2)) */
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s, w = z * z;
+    float t1 = w * fmaf(w, 0.24279078841f, 0.40000972152f);
+    float t2 = z * fmaf(w, 0.28498786688f, 0.66666662693f);
+    float R = t2 + t1;
+    float hfsq = 0.5f * (f * f);
+    float ln1pf = f - (hfsq - s * (hfsq + R));
+    return fmaf(ln1pf, 1.44269504088896341f, (float)e);
+}
+static float o_exp2f(float y) {                              /* fixed op order, |error| ~ 2e-7 relative */
+    y = fminf(fmaxf(y, -126.0f), 127.0f);
+    float n = rintf(y);
+    float r = y - n;                                         /* [-0.5, 0.5] */
+    float p = fmaf(r, 1.535336188319500e-4f, 1.339887440266574e-3f);
+    p = fmaf(p, r, 9.618437357674640e-3f);
+    p = fmaf(p, r, 5.550357186158072e-2f);
+    p = fmaf(p, r, 2.402264791363012e-1f);
+    p = fmaf(p, r, 6.931472028550421e-1f);
+    p = fmaf(p, r, 1.0f);
+    return p * o_bitsf((uint32_t)((int)n + 127) << 23);
+}
+float sph_oracle_powf(float x, float p) {                    /* GLSL pow for x >= 0 */
+    if (!(x > 0.0f)) return (p > 0.0f) ? 0.0f : ((p == 0.0f) ? 1.0f : INFINITY);
+    return o_exp2f(p * o_log2f(x));
+}
+
+/* Sampled curves of shapes 9 / 11 / 12 / 14: out[3*k..] (k < *count <= 128) and the initial
+ * "best" point the shader starts its nearest-sample search from. */
+int sph_oracle_shape_table(const OParams* p, float* out, float best0[3]) {
+    const float hx = p->boxHalf[0], hy = p->boxHalf[1];
+    int n = 0;
+    best0[0] = best0[1] = best0[2] = 0.0f;
+    switch (p->shapeType) {
+    case 9: {                                                /* trefoil :180-202 */
+        const float S = hx;
+        best0[0] = 3.0f * S;
+        for (int k = 0; k < 48; ++k) {
+            float t = 6.2831853f * (float)k / 48.0f;
+            out[3 * n + 0] = S * (sinf(t) + 2.0f * sinf(2.0f * t));
+            out[3 * n + 1] = S * (0.35f * (-sinf(3.0f * t)));
+            out[3 * n + 2] = S * (cosf(t) - 2.0f * cosf(2.0f * t));
+            ++n;
+        }
+        break;
+    }
+    case 11: case 14: {                                      /* DNA :224-241, coil :282-296 */
+        const float R = hx, r = hy;
+        const float turns = fmaxf(1.0f, p->shapeAux[0]), H = fmaxf(p->shapeAux[1], r);
+        best0[0] = R; best0[1] = -H;
+        for (int k = 0; k < 64; ++k) {
+            float f = (float)k / 63.0f;
+            float t = f * turns * 6.2831853f;
+            float y = (f - 0.5f) * 2.0f * H;
+            out[3 * n + 0] = R * cosf(t); out[3 * n + 1] = y; out[3 * n + 2] = R * sinf(t); ++n;
+            if (p->shapeType == 11) {
+                out[3 * n + 0] = R * cosf(t + 3.14159265f); out[3 * n + 1] = y; out[3 * n + 2] = R * sinf(t + 3.14159265f); ++n;
+            }
+        }
+        break;
+    }
+    case 12: {                                               /* heart :242-257 */
+        const float S = hx * 0.0625f;
+        for (int k = 0; k < 64; ++k) {
+            float t = 6.2831853f * (float)k / 64.0f;
+            float st = sinf(t);
+            float hxx = 16.0f * st * st * st;
+            float hyy = 13.0f * cosf(t) - 5.0f * cosf(2.0f * t) - 2.0f * cosf(3.0f * t) - cosf(4.0f * t);
+            out[3 * n + 0] = S * hxx; out[3 * n + 1] = S * hyy; out[3 * n + 2] = 0.0f; ++n;
+        }
+        break;
+    }
+    default: break;
+    }
+    return n;
+}
+
+/* Shapes 7..14; returns hit, fills qL / nL (local space). */
+static int o_shape_project_ext(const OObb* b, const float pL[3], float qL[3], float nL[3]) {
+    const float hx = b->half[0], hy = b->half[1];
+    switch (b->shape) {
+    case 7: {                                                /* star prism :144-163 */
+        float R = hx, H = hy;
+        float pts = fmaxf(3.0f, b->aux[0]);
+        float depth = o_clampf(b->aux[1], 0.0f, 0.9f);
+        float yC = o_clampf(pL[1], -H, H);
+        float ang = sph_oracle_atan2f(pL[2], pL[0]);
+        float rMax = R * (1.0f - depth * (0.5f + 0.5f * sph_oracle_cosf(pts * ang)));
+        float lxz = sqrtf(fmaf(pL[2], pL[2], pL[0] * pL[0]));
+        float qx = pL[0], qz = pL[2];
+        if (lxz > rMax) { float s = rMax / fmaxf(lxz, 1e-6f); qx = pL[0] * s; qz = pL[2] * s; }
+        qL[0] = qx; qL[1] = yC; qL[2] = qz;
+        float de[3] = { pL[0] - qL[0], pL[1] - qL[1], pL[2] - qL[2] };
+        float dl = sqrtf(o_dot3(de[0], de[1], de[2], de[0], de[1], de[2]));
+        if (dl > 1e-6f) { nL[0] = de[0] / dl; nL[1] = de[1] / dl; nL[2] = de[2] / dl; return 1; }
+        return 0;
+    }
+    case 8: {                                                /* superellipsoid :164-179 */
+        float a = fmaxf(hx, 1e-6f), bb = fmaxf(hy, 1e-6f);
+        float n = o_clampf(b->aux[2], 0.6f, 8.0f);
+        float e[3] = { a, bb, a };
+        float u[3] = { fabsf(pL[0]) / e[0], fabsf(pL[1]) / e[1], fabsf(pL[2]) / e[2] };
+        float F = (sph_oracle_powf(u[0], n) + sph_oracle_powf(u[1], n)) + sph_oracle_powf(u[2], n);
+        if (F > 1.0f) {
+            float s = sph_oracle_powf(F, -1.0f / n);
+            float g[3];
+            for (int k = 0; k < 3; ++k) {
+                qL[k] = pL[k] * s;
+                g[k] = (o_signf(pL[k]) * sph_oracle_powf(fmaxf(fabsf(qL[k]) / e[k], 1e-6f), n - 1.0f)) / e[k];
+            }
+            float gl = sqrtf(o_dot3(g[0], g[1], g[2], g[0], g[1], g[2]));
+            for (int k = 0; k < 3; ++k) nL[k] = g[k] / gl;
+            return 1;
+        }
+        return 0;
+    }
+    case 9: case 11: case 12: case 14: {                     /* nearest sample of a tabulated curve, then tube */
+        float r = hy;
+        float best[3] = { b->best0[0], b->best0[1], b->best0[2] };
+        float bestD2 = 1e30f;
+        for (int k = 0; k < b->tabCount; ++k) {
+            const float* c = b->tab + 3 * k;
+            float d0 = pL[0] - c[0], d1 = pL[1] - c[1], d2v = pL[2] - c[2];
+            float d2 = o_dot3(d0, d1, d2v, d0, d1, d2v);
+            if (d2 < bestD2) { bestD2 = d2; best[0] = c[0]; best[1] = c[1]; best[2] = c[2]; }
+        }
+        float d[3] = { pL[0] - best[0], pL[1] - best[1], pL[2] - best[2] };
+        float dl = sqrtf(o_dot3(d[0], d[1], d[2], d[0], d[1], d[2]));
+        if (dl > r) {
+            float m = fmaxf(dl, 1e-6f);
+            for (int k = 0; k < 3; ++k) { nL[k] = d[k] / m; qL[k] = best[k] + nL[k] * r; }
+            return 1;
+        }
+        return 0;
+    }
+    case 10: {                                               /* Moebius band :203-223 */
+        float R = hx, wHalf = hy, tHalf = fmaxf(b->aux[0], 0.05f);
+        float phi = sph_oracle_atan2f(pL[2], pL[0]);
+        float cp = sph_oracle_cosf(phi), sp = sph_oracle_sinf(phi);
+        float c[3] = { R * cp, 0.0f, R * sp };
+        float psi = 0.5f * phi;
+        float cps = sph_oracle_cosf(psi), sps = sph_oracle_sinf(psi);
+        float wA[3] = { cps * cp, sps, cps * sp };
+        float tA[3] = { (-sps) * cp, cps, (-sps) * sp };
+        float o[3] = { pL[0] - c[0], pL[1] - c[1], pL[2] - c[2] };
+        float cu = o_clampf(o_dot3(o[0], o[1], o[2], wA[0], wA[1], wA[2]), -wHalf, wHalf);
+        float cv = o_clampf(o_dot3(o[0], o[1], o[2], tA[0], tA[1], tA[2]), -tHalf, tHalf);
+        for (int k = 0; k < 3; ++k) qL[k] = (c[k] + cu * wA[k]) + cv * tA[k];
+        float de[3] = { pL[0] - qL[0], pL[1] - qL[1], pL[2] - qL[2] };
+        float dl = sqrtf(o_dot3(de[0], de[1], de[2], de[0], de[1], de[2]));
+        if (dl > 1e-5f) { nL[0] = de[0] / dl; nL[1] = de[1] / dl; nL[2] = de[2] / dl; return 1; }
+        return 0;
+    }
+    case 13: {                                               /* gyroid :258-281 */
+        float R = hx;
+        float sc = fmaxf(b->aux[0], 0.1f);
+        float th = o_clampf(b->aux[1], 0.2f, 2.5f);
+        float lp = sqrtf(o_dot3(pL[0], pL[1], pL[2], pL[0], pL[1], pL[2]));
+        if (lp > R) {
+            float m = fmaxf(lp, 1e-6f);
+            for (int k = 0; k < 3; ++k) { nL[k] = pL[k] / m; qL[k] = nL[k] * R; }
+            return 1;
+        }
+        float qx = pL[0] * sc, qy = pL[1] * sc, qz = pL[2] * sc;
+        float sx = sph_oracle_sinf(qx), cx = sph_oracle_cosf(qx), sy = sph_oracle_sinf(qy), cy = sph_oracle_cosf(qy);
+        float sz = sph_oracle_sinf(qz), cz = sph_oracle_cosf(qz);
+        float g = (sx * cy + sy * cz) + sz * cx;
+        if (fabsf(g) > th) {
+            float gr[3] = { sc * (cx * cy - sz * sx), sc * ((-sx) * sy + cy * cz), sc * ((-sy) * sz + cz * cx) };
+            float gl = fmaxf(sqrtf(o_dot3(gr[0], gr[1], gr[2], gr[0], gr[1], gr[2])), 1e-5f);
+            float sg = o_signf(g);
+            float step = (fabsf(g) - th) / gl;
+            for (int k = 0; k < 3; ++k) { nL[k] = (sg * gr[k]) / gl; qL[k] = pL[k] - nL[k] * step; }
+            return 1;
+        }
+        return 0;
+    }
+    default: return 0;
+    }
 }
 
 /* Shape projection: returns hit, fills qL and nL (local space). */
@@ -454,6 +712,7 @@ static void o_obb_one(OParticle* p, const OObb* b) {
 
 static int o_shape_project(const OObb* b, const float pL[3], float qL[3], float nL[3]) {
     const float hx = b->half[0], hy = b->half[1], hz = b->half[2];
+    if (b->shape >= 7 && b->shape <= 14) return o_shape_project_ext(b, pL, qL, nL);
     switch (b->shape) {
     case 1: {                                                /* sphere :60-68 */
         float R = hx;
@@ -546,10 +805,10 @@ static int o_shape_project(const OObb* b, const float pL[3], float qL[3], float 
     }
 }
 
-/* Shape types this oracle restates exactly (others fall through to box in
- * o_shape_project and must not be claimed): 0 box, 1 sphere, 2 cylinder, 3 torus,
- * 4 capsule, 5 hourglass, 6 egg. */
-int sph_oracle_shape_supported(int shape) { return shape >= 0 && shape <= 6; }
+/* Shape types this oracle restates: 0 box, 1 sphere, 2 cylinder, 3 torus, 4 capsule,
+ * 5 hourglass, 6 egg, 7 star, 8 superellipsoid, 9 trefoil, 10 Moebius, 11 DNA, 12 heart,
+ * 13 gyroid, 14 coil (anything else is the box branch, as in the shader's final else). */
+int sph_oracle_shape_supported(int shape) { return shape >= 0 && shape <= 14; }
 
 void sph_oracle_obb(OParticle* P, int n, const OParams* p) {
     OObb b;
@@ -621,7 +880,7 @@ static float o_pcg_uniform(OPcg* r, float lo, float hi) {
     return lo + u * (hi - lo);
 }
 
-/* insideShape lambda, SPHFluid3D.cpp:167-289 (shapes 0..6 restated) */
+/* insideShape lambda, SPHFluid3D.cpp:167-289.  Host code in the reference too: libm here. */
 static int o_inside_shape(const OParams* p, const float hf[3], float margin, float lx, float ly, float lz) {
     switch (p->shapeType) {
     case 1: { float r = hf[0] - margin; return lx * lx + ly * ly + lz * lz <= r * r; }
@@ -640,6 +899,43 @@ static int o_inside_shape(const OParams* p, const float hf[3], float margin, flo
     case 6: { float a = fmaxf(p->boxHalf[0] - margin, 1e-4f), b = fmaxf(p->boxHalf[1] - margin, 1e-4f);
               float u = lx / a, v = ly / b, w = lz / a;
               return (u * u + v * v + w * w) <= 1.0f; }
+    case 7: { float R = p->boxHalf[0], H = p->boxHalf[1];
+              float pts = fmaxf(3.0f, p->shapeAux[0]), depth = o_clampf(p->shapeAux[1], 0.0f, 0.9f);
+              if (fabsf(ly) > H - margin) return 0;
+              float ang = atan2f(lz, lx);
+              float rMax = R * (1.0f - depth * (0.5f + 0.5f * cosf(pts * ang))) - margin;
+              return rMax > 0.0f && (lx * lx + lz * lz) <= rMax * rMax; }
+    case 8: { float a = fmaxf(p->boxHalf[0] - margin, 1e-4f), b = fmaxf(p->boxHalf[1] - margin, 1e-4f);
+              float n = o_clampf(p->shapeAux[2], 0.6f, 8.0f);
+              float F = powf(fabsf(lx) / a, n) + powf(fabsf(ly) / b, n) + powf(fabsf(lz) / a, n);
+              return F <= 1.0f; }
+    case 9: case 11: case 12: case 14: {
+              float r = p->boxHalf[1] - margin;
+              if (r <= 0.0f) return 0;
+              float tab[384], b0[3];
+              int cnt = sph_oracle_shape_table(p, tab, b0);   /* same samples as the shader (H, S unshrunk, :216-262) */
+              float bestD2 = 1e30f;
+              for (int k = 0; k < cnt; ++k) {
+                  float dx = lx - tab[3 * k], dy = ly - tab[3 * k + 1], dz = lz - tab[3 * k + 2];
+                  bestD2 = fminf(bestD2, dx * dx + dy * dy + dz * dz);
+              }
+              return bestD2 <= r * r; }
+    case 10: { float R = p->boxHalf[0], wHalf = p->boxHalf[1] - margin, tHalf = fmaxf(p->shapeAux[0], 0.05f) - margin;
+              if (wHalf <= 0.0f || tHalf <= 0.0f) return 0;
+              float phi = atan2f(lz, lx);
+              float erx = cosf(phi), erz = sinf(phi);
+              float ox = lx - R * erx, oy = ly, oz = lz - R * erz;
+              float psi = 0.5f * phi;
+              float cw = cosf(psi), sw = sinf(psi);
+              float du = ox * (cw * erx) + oy * (sw) + oz * (cw * erz);
+              float dv = ox * (-sw * erx) + oy * (cw) + oz * (-sw * erz);
+              return fabsf(du) <= wHalf && fabsf(dv) <= tHalf; }
+    case 13: { float R = p->boxHalf[0] - margin;
+              float sc = fmaxf(p->shapeAux[0], 0.1f), th = o_clampf(p->shapeAux[1], 0.2f, 2.5f);
+              if (lx * lx + ly * ly + lz * lz > R * R) return 0;
+              float qx = lx * sc, qy = ly * sc, qz = lz * sc;
+              float g = sinf(qx) * cosf(qy) + sinf(qy) * cosf(qz) + sinf(qz) * cosf(qx);
+              return fabsf(g) <= th; }
     default: return 1;
     }
 }

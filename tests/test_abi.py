@@ -59,10 +59,11 @@ def test_host_helpers_match_oracle(pkg, oracle):
             assert list(a.gridMin) == list(b.gridMin) and a.cellSize == b.cellSize
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", list(range(15)))
 @pytest.mark.parametrize("mix,dye,jit", [(0, 0, 1), (1, 1, 1), (2, 2, 1), (0, 2, 0)])
 def test_spawn_matches_oracle(pkg, oracle, shape, mix, dye, jit):
     sp = pkg.default_params(param_shapeType=shape, param_boxHalf=(4.0, 3.0, 2.5), param_boxCenter=(0.5, 1.0, -1.0),
+                            param_shapeAux=(3.0, 0.6, 3.0),
                             param_mixPattern=mix, param_dyePattern=dye, param_useJitter=jit)
     a, ma = pkg.spawn_particles(sp, 20000, seed=77)
     b, mb = oracle.spawn(to_oracle_params(oracle, sp), 20000, seed=77)

@@ -128,11 +128,12 @@ def test_hard_scene(pkg, oracle, name, neighbor):
     f.close()
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", list(range(15)))
 def test_container_shapes(pkg, oracle, shape):
-    """OBBConstraints.comp shapes 0..6 (box, sphere, cylinder, torus, capsule, hourglass, egg)."""
+    """OBBConstraints.comp shapes 0..14 (box, sphere, cylinder, torus, capsule, hourglass, egg, star,
+    superellipsoid, trefoil, Moebius, DNA, heart, gyroid, coil); 7..14 run as the k_obb_ext pass."""
     sp = pkg.default_params(param_shapeType=shape, param_boxHalf=(2.2, 1.6, 0.9), param_boxEulerDeg=(10.0, -25.0, 40.0),
-                            param_boxCenter=(0.2, -0.1, 0.3))
+                            param_boxCenter=(0.2, -0.1, 0.3), param_shapeAux=(3.0, 0.6, 3.0))
     rec, mass = pkg.spawn_particles(sp, 5000, seed=5)
     sp.param_mass = mass
     rng = np.random.default_rng(shape)
@@ -143,10 +144,39 @@ def test_container_shapes(pkg, oracle, shape):
     f.close()
 
 
-def test_unimplemented_shapes_fail_loudly(pkg):
-    sp = pkg.default_params(param_shapeType=9)
-    with pytest.raises(pkg.SphError, match="not implemented"):
-        pkg.SPHFluidGPU(1000, params=sp)
+@pytest.mark.parametrize("neighbor,aos", [(1, 0), (0, 1)])
+def test_ext_shape_other_paths(pkg, oracle, neighbor, aos):
+    """A deferred-OBB shape through the gather kernel and with the lazy 80-byte array; the shape
+    changes between dispatches (table re-upload), as the ImGui shape picker does (Scene0p.cpp:2380-2470)."""
+    sp = pkg.default_params(param_shapeType=11, param_boxHalf=(2.0, 0.9, 1.0), param_shapeAux=(2.0, 2.5, 3.0))
+    rec, mass = pkg.spawn_particles(sp, 4000, seed=9)
+    assert len(rec) > 500
+    sp.param_mass = mass
+    rec["vel"][:, :3] = np.random.default_rng(4).normal(0, 15, (len(rec), 3)).astype(np.float32)
+    f = make_engine(pkg, rec, sp, neighbor)
+    f.set_option(pkg.SPH_OPT_AOS_MODE, aos)
+    f.DispatchN(3)
+    want = oracle.substep(rec, to_oracle_params(oracle, sp), steps=3)
+    for shape, half in ((14, (2.0, 0.9, 1.0)), (12, (3.0, 0.8, 1.0)), (2, (2.5, 2.5, 2.5)), (9, (1.2, 0.9, 1.0))):
+        f.param_shapeType, f.param_boxHalf = shape, half            # public member writes, read at the next dispatch
+        sp.param_shapeType = shape
+        for i in range(3):
+            sp.param_boxHalf[i] = half[i]
+        f.DispatchN(2)
+        want = oracle.substep(want, to_oracle_params(oracle, sp), steps=2)
+    assert_records_equal(f.download(), want, "shape sequence")
+    f.close()
+
+
+def test_unknown_shape_is_box(pkg, oracle):
+    """shapeType outside 1..14 takes the shader's final else (box), OBBConstraints.comp:297."""
+    rec, sp = small_scene(pkg, n=4096, grid=16, seed=35)
+    sp.param_shapeType = 99
+    f = make_engine(pkg, rec, sp)
+    f.DispatchN(3)
+    sp0 = to_oracle_params(oracle, sp)
+    assert_records_equal(f.download(), oracle.substep(rec, sp0, steps=3), "shape 99")
+    f.close()
 
 
 def test_reference_style_lifecycle(pkg, oracle):

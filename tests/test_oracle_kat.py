@@ -301,3 +301,140 @@ def test_spawn(oracle):
     p.useJitter = 0
     Q, _ = oracle.spawn(p, 1000, seed=4)
     assert np.allclose(np.diff(Q["pos"][:50, 2]), s, rtol=1e-5)
+
+
+# ---- container shapes 7..14 (OBBConstraints.comp:144-296) ---------------------------------
+
+def test_pinned_cos_atan2_pow_accuracy(oracle):
+    """The fixed fp32 cos / atan2 / pow (oracle semantic 10) against float64 libm."""
+    rng = np.random.default_rng(3)
+    xs = rng.uniform(-40, 40, 4000).astype(np.float32)
+    assert max(abs(oracle.cosf(x) - np.cos(np.float64(x))) for x in xs) < 2e-7
+    ys, xx = rng.normal(size=4000).astype(np.float32), rng.normal(size=4000).astype(np.float32)
+    assert max(abs(oracle.atan2f(y, x) - np.arctan2(np.float64(y), np.float64(x))) for y, x in zip(ys, xx)) < 5e-7
+    b, pw = rng.uniform(1e-6, 30, 4000).astype(np.float32), rng.uniform(-3, 8, 4000).astype(np.float32)
+    for x, p in zip(b, pw):
+        r = np.float64(x) ** np.float64(p)
+        if 1e-30 < r < 1e30:
+            assert abs(oracle.powf(x, p) - r) / r < 5e-6
+    assert oracle.powf(0.0, 2.0) == 0.0 and oracle.powf(1.0, 7.0) == 1.0 and oracle.powf(3.0, 0.0) == 1.0
+    assert oracle.atan2f(0.0, 0.0) == 0.0 and oracle.atan2f(1.0, 0.0) == np.float32(np.pi / 2)
+    assert oracle.atan2f(0.0, -1.0) == np.float32(np.pi) and oracle.cosf(0.0) == 1.0
+
+
+def _ext_shape_float64(shape, half, aux, p):
+    """Independent float64 numpy statement of the shader's projection for shapes 7..14:
+    returns (hit, q) per point."""
+    hx, hy = half[0], half[1]
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    q = p.copy()
+    hit = np.zeros(len(p), bool)
+
+    def tube(c, best0, r):
+        d2 = ((p[:, None, :] - c[None, :, :]) ** 2).sum(-1)
+        k = d2.argmin(1)
+        best = c[k]
+        d = p - best
+        dl = np.sqrt((d * d).sum(1))
+        h = dl > r
+        nl = d / np.maximum(dl, 1e-6)[:, None]
+        return h, np.where(h[:, None], best + nl * r, p), np.sort(d2, 1)
+
+    if shape == 7:
+        pts, depth = max(3.0, aux[0]), np.clip(aux[1], 0.0, 0.9)
+        ang = np.arctan2(z, x)
+        rmax = hx * (1 - depth * (0.5 + 0.5 * np.cos(pts * ang)))
+        lxz = np.hypot(x, z)
+        s = np.where(lxz > rmax, rmax / np.maximum(lxz, 1e-6), 1.0)
+        q = np.stack([x * s, np.clip(y, -hy, hy), z * s], 1)
+        hit = np.sqrt(((p - q) ** 2).sum(1)) > 1e-6
+    elif shape == 8:
+        a, b, n = max(hx, 1e-6), max(hy, 1e-6), np.clip(aux[2], 0.6, 8.0)
+        e = np.array([a, b, a])
+        F = ((np.abs(p) / e) ** n).sum(1)
+        hit = F > 1
+        q = np.where(hit[:, None], p * (F ** (-1.0 / n))[:, None], p)
+    elif shape == 9:
+        t = 6.2831853 * np.arange(48) / 48.0
+        c = hx * np.stack([np.sin(t) + 2 * np.sin(2 * t), 0.35 * -np.sin(3 * t), np.cos(t) - 2 * np.cos(2 * t)], 1)
+        return tube(c, None, hy)
+    elif shape in (11, 14):
+        turns, H = max(1.0, aux[0]), max(aux[1], hy)
+        f = np.arange(64) / 63.0
+        t = f * turns * 6.2831853
+        c = np.stack([hx * np.cos(t), (f - 0.5) * 2 * H, hx * np.sin(t)], 1)
+        if shape == 11:
+            c = np.concatenate([c, np.stack([hx * np.cos(t + 3.14159265), (f - 0.5) * 2 * H, hx * np.sin(t + 3.14159265)], 1)])
+        return tube(c, None, hy)
+    elif shape == 12:
+        t = 6.2831853 * np.arange(64) / 64.0
+        S = hx * 0.0625
+        c = np.stack([S * 16 * np.sin(t) ** 3, S * (13 * np.cos(t) - 5 * np.cos(2 * t) - 2 * np.cos(3 * t) - np.cos(4 * t)), 0 * t], 1)
+        return tube(c, None, hy)
+    elif shape == 10:
+        R, wH, tH = hx, hy, max(aux[0], 0.05)
+        phi = np.arctan2(z, x)
+        er = np.stack([np.cos(phi), 0 * phi, np.sin(phi)], 1)
+        ey = np.array([0.0, 1.0, 0.0])[None, :]
+        psi = 0.5 * phi
+        w = np.cos(psi)[:, None] * er + np.sin(psi)[:, None] * ey
+        tt = -np.sin(psi)[:, None] * er + np.cos(psi)[:, None] * ey
+        c = R * er
+        o = p - c
+        cu = np.clip((o * w).sum(1), -wH, wH)
+        cv = np.clip((o * tt).sum(1), -tH, tH)
+        q = c + cu[:, None] * w + cv[:, None] * tt
+        hit = np.sqrt(((p - q) ** 2).sum(1)) > 1e-5
+    elif shape == 13:
+        R, sc, th = hx, max(aux[0], 0.1), np.clip(aux[1], 0.2, 2.5)
+        lp = np.sqrt((p * p).sum(1))
+        out = lp > R
+        qq = p * sc
+        sx, sy, sz, cx, cy, cz = np.sin(qq[:, 0]), np.sin(qq[:, 1]), np.sin(qq[:, 2]), np.cos(qq[:, 0]), np.cos(qq[:, 1]), np.cos(qq[:, 2])
+        g = sx * cy + sy * cz + sz * cx
+        grad = sc * np.stack([cx * cy - sz * sx, -sx * sy + cy * cz, -sy * sz + cz * cx], 1)
+        gl = np.maximum(np.sqrt((grad * grad).sum(1)), 1e-5)
+        nl = np.sign(g)[:, None] * grad / gl[:, None]
+        inner = (~out) & (np.abs(g) > th)
+        q = np.where(out[:, None], p / np.maximum(lp, 1e-6)[:, None] * R, np.where(inner[:, None], p - nl * ((np.abs(g) - th) / gl)[:, None], p))
+        hit = out | inner
+        return hit, q, np.abs(np.abs(g) - th)
+    return hit, q, None
+
+
+@pytest.mark.parametrize("shape", list(range(7, 15)))
+def test_obb_ext_shapes_match_float64_statement(oracle, shape):
+    """Shapes 7..14: the oracle's projected positions against an independent float64 numpy
+    statement of the shader (identity rotation, centred container)."""
+    rng = np.random.default_rng(100 + shape)
+    n = 3000
+    half, aux = (3.0, 1.2, 1.0), (4.0, 0.5, 3.0)
+    P = np.zeros(n, oracle.PARTICLE_DTYPE)
+    P["pos"][:, :3] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    P["vel"][:, :3] = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    P["isActive"] = 1
+    p = oracle.default_params(shapeType=shape, boxHalf=half, shapeAux=aux, boxCenter=(0, 0, 0), boxEulerDeg=(0, 0, 0))
+    assert oracle.lib().sph_oracle_shape_supported(shape)
+    out = oracle.obb(P, p)
+    hit, q, aux_metric = _ext_shape_float64(shape, half, aux, P["pos"][:, :3].astype(np.float64))
+    moved = (out["pos"][:, :3] != P["pos"][:, :3]).any(1)
+    # decisions can only differ for points within rounding of a threshold (or nearly equidistant samples)
+    if shape in (9, 11, 12, 14):
+        robust = (aux_metric[:, 1] - aux_metric[:, 0]) > 1e-3          # clear nearest sample
+        robust &= np.abs(np.sqrt(aux_metric[:, 0]) - half[1]) > 1e-4
+    elif shape == 13:
+        robust = (aux_metric > 1e-4) & (np.abs(np.sqrt((P["pos"][:, :3].astype(np.float64) ** 2).sum(1)) - half[0]) > 1e-4)
+    elif shape == 8:
+        robust = np.abs(((np.abs(P["pos"][:, :3].astype(np.float64)) / np.array([3.0, 1.2, 3.0])) ** 3.0).sum(1) - 1) > 1e-4
+    else:
+        robust = np.sqrt(((P["pos"][:, :3] - q) ** 2).sum(1)) > 1e-4
+        robust |= ~hit
+    assert robust.mean() > 0.95 and hit.sum() > n // 4
+    assert np.array_equal(moved[robust], hit[robust])
+    err = np.abs(out["pos"][:, :3].astype(np.float64) - q)[robust]
+    assert err.max() < 5e-5, (shape, err.max())
+    # response: the normal velocity component is reflected with restitution, tangential damped -> speed never grows
+    v0 = np.sqrt((P["vel"][:, :3].astype(np.float64) ** 2).sum(1))
+    v1 = np.sqrt((out["vel"][:, :3].astype(np.float64) ** 2).sum(1))
+    assert np.all(v1 <= v0 * (1 + 1e-5))
+    assert np.array_equal(out["vel"][~moved], P["vel"][~moved])
