@@ -7,7 +7,7 @@ importlib.import_module("componentframeworks-smoothed-particle-hydrodynamics_amd
 """
 from .engine import (  # noqa: F401
     ABI_SYMBOLS, KERNEL_CLASSES, PARTICLE_DTYPE, SPH_OPT_AOS_MODE, SPH_OPT_DEBUG, SPH_OPT_GRID_BUILD,
-    SPH_OPT_NEIGHBOR_KERNEL, SPH_OPT_TIMING, SPHFluidGPU, SphError, SphGridInfo, SphParams,
+    SPH_OPT_NEIGHBOR_KERNEL, SPH_OPT_TIMING, SPHFluidGPU, SphError, SphFountain, SphGridInfo, SphParams,
     compute_grid_extents, default_params, effective_half, load_library, rotation_mat3, spawn_particles,
 )
 from . import build, synthetic  # noqa: F401

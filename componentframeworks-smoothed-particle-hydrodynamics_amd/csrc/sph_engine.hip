@@ -97,6 +97,7 @@ struct SphEngine {
     bool slab = false;
     int z0 = 0, z1 = 0, hasLo = 0, hasHi = 0;
     size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count
+    SphFountain fountain{};                 // fountain* members (SPHFluid3D.h:161-168)
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
     float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
     sph::ShapeTab shapeTab{};
@@ -369,6 +370,23 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         const uint32_t* live = (e->slab && e->optGridBuild != 1) ? e->d_cellStart + k.numCells : nullptr;
         hipLaunchKernelGGL(k_obb_ext, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->shapeTab, out.pos, out.vel, live, n);
     }
+    if (e->fountain.fountainMode) {                                         // :519, :526-544
+        if (n) {
+            float half[3];
+            effective_half(e->params, half);
+            const SphParams& p = e->params;
+            const SphFountain& f = e->fountain;
+            FountainK fk{p.param_boxCenter[0] + f.fountainOffset[0], p.param_boxCenter[1] + f.fountainOffset[1],
+                         p.param_boxCenter[2] + f.fountainOffset[2], f.fountainRadius, f.fountainSpread, f.fountainJetSpeedLive,
+                         (p.param_boxCenter[1] - half[1]) + f.fountainDrainLevel, std::fmin(1.0f, f.fountainDrainPerSec * dt),
+                         p.param_restDensity, f.fountainSeed * 747796405u};
+            Timed t(e, SPH_K_OTHER);
+            const uint32_t* live = (e->slab && e->optGridBuild != 1) ? e->d_cellStart + k.numCells : nullptr;
+            hipLaunchKernelGGL(k_fountain, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, fk, out.pos, out.vel, out.rp,
+                               fuseAos ? (float4*)nullptr : e->d_acc, fuseAos ? e->d_aos : (SphParticle*)nullptr, e->idBase, live, n);
+        }
+        e->fountain.fountainSeed++;
+    }
     HIP_TRY(hipGetLastError());
     e->cur = nx;
     e->accValid = !fuseAos;
@@ -446,6 +464,7 @@ static int create_common(SphEngine** out, const SphParams* params, void* stream,
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(SPH_ERR_HIP, "no HIP device: this engine has no CPU fallback");
     SphEngine* e = new SphEngine();
+    sph_fountain_default(&e->fountain);
     e->params = *params;
     if (stream) { e->stream = (hipStream_t)stream; e->ownStream = false; }
     else {
@@ -655,6 +674,21 @@ int sph_apply_curl_flow(SphEngine* e, float kick, float scale, float time) {    
     CurlK kk;
     kk.kick = kick; kk.scale = std::fmax(scale, 1e-3f); kk.time = time;
     return launch_impulse(e, kk);
+}
+
+void sph_fountain_default(SphFountain* out) {               // SPHFluid3D.h:161-168
+    if (!out) return;
+    *out = SphFountain{0, {0.0f, -5.0f, 0.0f}, 1.0f, 0.25f, 25.0f, 1.0f, 2.0f, 0u};
+}
+int sph_set_fountain(SphEngine* e, const SphFountain* f) {
+    if (!e || !f) return fail(SPH_ERR_ARG, "null argument");
+    e->fountain = *f;
+    return SPH_OK;
+}
+int sph_get_fountain(const SphEngine* e, SphFountain* out) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    *out = e->fountain;
+    return SPH_OK;
 }
 
 size_t sph_num_particles(const SphEngine* e) { return e ? e->n : 0; }

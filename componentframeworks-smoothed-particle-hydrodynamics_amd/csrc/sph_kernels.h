@@ -262,6 +262,54 @@ __global__ __launch_bounds__(kBlock) void k_obb_ext(SimK k, ShapeTab T, float4* 
     pos[s] = P; vel[s] = V;
 }
 
+// shaders/FountainRecycle.comp:24-54 on the SPH pass's output state.  The particle index of the
+// shader is the (global) id kept in vel.w; cos / sin are the pinned routines.
+struct FountainK {
+    float ex, ey, ez;          // uEmitterPos
+    float radius, spread, jet; // uEmitterRadius, uJetSpread, uJetSpeed
+    float drainY, chance, rho0;
+    uint32_t seedMul;          // uSeed * 747796405u
+};
+__device__ __forceinline__ float lcg_next(uint32_t& s) {
+    s = s * 1664525u + 1013904223u;
+    return (float)(s & 0xFFFFFFu) / 16777215.0f;
+}
+__global__ __launch_bounds__(kBlock) void k_fountain(FountainK f, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                     float2* __restrict__ rp, float4* __restrict__ acc, SphParticle* __restrict__ aos,
+                                                     uint32_t idBase, const uint32_t* __restrict__ liveCount, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const int bound = liveCount ? min(n, (int)*liveCount) : n;
+    if (s >= bound) return;
+    const float4 P = pos[s];
+    const uint32_t flags = fbits(P.w);
+    if (flags & (F_GHOST1 | F_HALO)) return;                 // :34 (isGhost == 1 only)
+    if (P.y >= f.drainY) return;                             // :35
+    const float4 V = vel[s];
+    const uint32_t id = fbits(V.w);
+    uint32_t seed = (id ^ f.seedMul) + 2891336453u;
+    if (lcg_next(seed) > f.chance) return;                   // :38
+    const float r1 = lcg_next(seed), r2 = lcg_next(seed), r3 = lcg_next(seed), r4 = lcg_next(seed);
+    const float ang = 6.2831853f * r1;
+    const float rad = f.radius * sqrtf(r2);
+    const float ca = sph_cosf(ang), sa = sph_sinf(ang);
+    const float px = f.ex + ca * rad, py = f.ey + 0.2f * r3, pz = f.ez + sa * rad;
+    const float sm = f.spread * r4;
+    const float sx = ca * sm, sz = sa * sm;
+    const float len = sqrtf(dot3(sx, 1.0f, sz, sx, 1.0f, sz));
+    const float vx = f.jet * (sx / len), vy = f.jet * (1.0f / len), vz = f.jet * (sz / len);
+    pos[s] = make_float4(px, py, pz, P.w);
+    vel[s] = make_float4(vx, vy, vz, V.w);
+    rp[s] = make_float2(f.rho0, 0.0f);
+    if (acc) acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (aos) {
+        float* rec = reinterpret_cast<float*>(aos + (id - idBase));
+        rec[0] = px; rec[1] = py; rec[2] = pz;
+        rec[4] = vx; rec[5] = vy; rec[6] = vz;
+        *reinterpret_cast<float4*>(rec + 8) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rec[12] = f.rho0; rec[13] = 0.0f;
+    }
+}
+
 // SPHFluid.comp main() for the particle in sorted slot s, neighbours gathered from global
 // memory through order[] (variant A, and the exact fallback of the tiled kernel).
 __device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in, const StateOut& out,

@@ -53,6 +53,13 @@ class SphParams(C.Structure):
     ]
 
 
+class SphFountain(C.Structure):
+    """fountain* members of the reference class (SPHFluid3D.h:161-168), same names."""
+    _fields_ = [("fountainMode", C.c_int32), ("fountainOffset", C.c_float * 3), ("fountainRadius", C.c_float),
+                ("fountainSpread", C.c_float), ("fountainJetSpeedLive", C.c_float), ("fountainDrainLevel", C.c_float),
+                ("fountainDrainPerSec", C.c_float), ("fountainSeed", C.c_uint32)]
+
+
 class SphGridInfo(C.Structure):
     _fields_ = [("dims", C.c_int32 * 3), ("numCells", C.c_int32), ("gridMin", C.c_float * 3), ("cellSize", C.c_float)]
 
@@ -70,7 +77,7 @@ ABI_SYMBOLS = (
     "sph_num_particles", "sph_grid_info", "sph_upload_particles", "sph_download_particles",
     "sph_device_particles", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
     "sph_debug_counters", "sph_apply_vortex_impulse", "sph_apply_attractor_impulse", "sph_set_stencil_targets",
-    "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
+    "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
 )
 STAMP_NAMES = ("prologue", "stage", "lists", "scan", "sweep2", "sweep3", "epilogue", "total", "tiles", "slices", "waverounds",
                "scangroups", "overflow_slices", "slow_lanes", "targets", "candidates", "walk2max", "walk2sum", "rescan_lanes",
@@ -143,13 +150,16 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_set_stencil_targets.argtypes = [vp, vp, C.c_size_t]
     L.sph_apply_stencil_attract.argtypes = [vp, C.c_float, C.c_float]
     L.sph_apply_curl_flow.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    L.sph_fountain_default.argtypes = [C.POINTER(SphFountain)]
+    L.sph_set_fountain.argtypes = [vp, C.POINTER(SphFountain)]
+    L.sph_get_fountain.argtypes = [vp, C.POINTER(SphFountain)]
     L.sph_create_slab.argtypes = [C.POINTER(vp), vp, vp, C.c_size_t, pp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp]
     L.sph_slab_pack.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.sph_slab_unpack.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     L.sph_slab_download.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version"):
+        if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version", "sph_fountain_default"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -205,6 +215,7 @@ def spawn_particles(p: SphParams, n_requested: int, seed: int):
 
 
 _PARAM_NAMES = {f[0] for f in SphParams._fields_}
+_FOUNTAIN_NAMES = {f[0] for f in SphFountain._fields_}
 
 
 class SPHFluidGPU:
@@ -220,6 +231,8 @@ class SPHFluidGPU:
         object.__setattr__(self, "_L", L)
         object.__setattr__(self, "_p", params if params is not None else default_params())
         object.__setattr__(self, "_h", C.c_void_p())
+        object.__setattr__(self, "_f", SphFountain())
+        L.sph_fountain_default(C.byref(self._f))
         object.__setattr__(self, "numParticles", int(numParticles_))
         object.__setattr__(self, "seed", int(seed))
         if _particles is not None:
@@ -235,19 +248,20 @@ class SPHFluidGPU:
 
     # -- public param_* members ----------------------------------------------------------
     def __getattr__(self, name):
-        if name in _PARAM_NAMES:
-            v = getattr(object.__getattribute__(self, "_p"), name)
+        if name in _PARAM_NAMES or name in _FOUNTAIN_NAMES:
+            v = getattr(object.__getattribute__(self, "_p" if name in _PARAM_NAMES else "_f"), name)
             return list(v) if hasattr(v, "__len__") else v
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if name in _PARAM_NAMES:
-            cur = getattr(self._p, name)
+        if name in _PARAM_NAMES or name in _FOUNTAIN_NAMES:
+            st = self._p if name in _PARAM_NAMES else self._f
+            cur = getattr(st, name)
             if hasattr(cur, "__len__"):
                 for i, x in enumerate(value):
                     cur[i] = x
             else:
-                setattr(self._p, name, value)
+                setattr(st, name, value)
         else:
             object.__setattr__(self, name, value)
 
@@ -256,15 +270,21 @@ class SPHFluidGPU:
         return self._p
 
     # -- reference methods ---------------------------------------------------------------
-    def DispatchCompute(self, overrideDt: float = -1.0):            # SPHFluid3D.cpp:431
+    def _push_members(self):
         _check(self._L.sph_set_params(self._h, C.byref(self._p)))  # members are re-read every dispatch (:458-506)
+        _check(self._L.sph_set_fountain(self._h, C.byref(self._f)))  # fountain* members (:519-541)
+
+    def DispatchCompute(self, overrideDt: float = -1.0):            # SPHFluid3D.cpp:431
+        self._push_members()
         _check(self._L.sph_dispatch(self._h, overrideDt))
+        _check(self._L.sph_get_fountain(self._h, C.byref(self._f)))  # fountainSeed++ (:541)
 
     SimulateSubstep = DispatchCompute   # BASELINE.json's name for the same entry point
 
     def DispatchN(self, n: int, overrideDt: float = -1.0):           # Scene0p.cpp:3720-3739 loop
-        _check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        self._push_members()
         _check(self._L.sph_dispatch_n(self._h, overrideDt, int(n)))
+        _check(self._L.sph_get_fountain(self._h, C.byref(self._f)))
 
     def ResetSimulation(self, seed: int | None = None):             # SPHFluid3D.cpp:713
         if seed is not None:

@@ -60,7 +60,11 @@ public:
     void DispatchCompute(float overrideDt = -1.0f) {                    // SPHFluid3D.cpp:431
         SphParams p = ToParams();                                       // members are re-read every dispatch (:458-506)
         if (Check(sph_set_params(engine, &p), "sph_set_params")) return;
+        SphFountain f{fountainMode ? 1 : 0, {fountainOffset.x, fountainOffset.y, fountainOffset.z}, fountainRadius, fountainSpread,
+                      fountainJetSpeedLive, fountainDrainLevel, fountainDrainPerSec, fountainSeed};
+        if (Check(sph_set_fountain(engine, &f), "sph_set_fountain")) return;
         if (Check(sph_dispatch(engine, overrideDt), "sph_dispatch")) return;
+        if (fountainMode && !param_pause) ++fountainSeed;               // glUniform1ui("uSeed", fountainSeed++), :541
         RefreshGrid();
     }
     void SimulateSubstep(float overrideDt = -1.0f) { DispatchCompute(overrideDt); }   // BASELINE.json's name
@@ -158,6 +162,15 @@ public:
     int param_dyePattern = 0;
     float param_wallRestitution = 0.15f;
     float param_wallFriction = 0.02f;
+    // fountain members, SPHFluid3D.h:161-168 (step 6 of DispatchCompute, :519)
+    bool fountainMode = false;
+    MATH::Vec3 fountainOffset = MATH::Vec3(0.0f, -5.0f, 0.0f);
+    float fountainRadius = 1.0f;
+    float fountainSpread = 0.25f;
+    float fountainJetSpeedLive = 25.0f;
+    float fountainDrainLevel = 1.0f;
+    float fountainDrainPerSec = 2.0f;
+    unsigned fountainSeed = 0;
     int grid_cap = 160;                        // engine extension (SPHFluid3D.cpp:370 hard-codes 160)
     uint32_t seed;                             // engine extension (the reference seeds from time(nullptr), :99)
 

@@ -96,6 +96,17 @@ typedef struct SphGridInfo {       /* gridSizeX/Y/Z, numCells, gridMinV, cellSiz
     float cellSize;
 } SphGridInfo;
 
+typedef struct SphFountain {       /* public fountain* members of SPHFluidGPU, SPHFluid3D.h:161-168 (same names) */
+    int32_t fountainMode;          /* bool fountainMode = false */
+    float fountainOffset[3];       /* nozzle, container-relative (0,-5,0) */
+    float fountainRadius;          /* 1.0 */
+    float fountainSpread;          /* 0.25 */
+    float fountainJetSpeedLive;    /* 25.0, written per frame by the scene */
+    float fountainDrainLevel;      /* 1.0 */
+    float fountainDrainPerSec;     /* 2.0 */
+    uint32_t fountainSeed;         /* advances by one per dispatch (SPHFluid3D.cpp:541) */
+} SphFountain;
+
 typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHFluidGPU owns its GL buffers, SPHFluid3D.cpp:61-83) */
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
@@ -171,6 +182,13 @@ int sph_set_stencil_targets(SphEngine* e, const float* points4, size_t count);
 int sph_apply_stencil_attract(SphEngine* e, float pullKick, float dampKick);
 /* SPHFluidGPU::ApplyCurlFlow, SPHFluid3D.cpp:668-681 + shaders/CurlFlow.comp. */
 int sph_apply_curl_flow(SphEngine* e, float kick, float scale, float time);
+
+/* Fountain recycle = DispatchCompute step 6 (SPHFluid3D.cpp:519, DispatchFountainRecycle :526-544,
+ * shaders/FountainRecycle.comp): while fountainMode is set every dispatch ends with the recycle
+ * pass and advances fountainSeed.  sph_get_fountain returns the current values (seed included). */
+void sph_fountain_default(SphFountain* out);             /* SPHFluid3D.h:161-168 initialisers */
+int sph_set_fountain(SphEngine* e, const SphFountain* f);
+int sph_get_fountain(const SphEngine* e, SphFountain* out);
 
 /* ---- data ------------------------------------------------------------------------ */
 size_t sph_num_particles(const SphEngine* e);            /* particles.size() / GetNumFluids() */

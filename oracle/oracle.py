@@ -192,13 +192,44 @@ def obb(P: np.ndarray, p: OParams) -> np.ndarray:
     return out
 
 
-def substep(P: np.ndarray, p: OParams, dt: float = -1.0, steps: int = 1) -> np.ndarray:
-    """DispatchCompute x steps; returns a new array."""
+class OFountain(C.Structure):
+    """fountain* members of SPHFluidGPU (SPHFluid3D.h:161-168)."""
+    _fields_ = [("mode", C.c_int32), ("offset", C.c_float * 3), ("radius", C.c_float), ("spread", C.c_float),
+                ("jetSpeedLive", C.c_float), ("drainLevel", C.c_float), ("drainPerSec", C.c_float), ("seed", C.c_uint32)]
+
+
+def default_fountain(**kw) -> OFountain:
+    f = OFountain(0, (C.c_float * 3)(0.0, -5.0, 0.0), 1.0, 0.25, 25.0, 1.0, 2.0, 0)
+    for k, v in kw.items():
+        if k == "offset":
+            for i in range(3):
+                f.offset[i] = v[i]
+        else:
+            setattr(f, k, v)
+    return f
+
+
+def substep(P: np.ndarray, p: OParams, dt: float = -1.0, steps: int = 1, fountain: "OFountain | None" = None) -> np.ndarray:
+    """DispatchCompute x steps; returns a new array.  `fountain` (its seed advances in place)
+    adds step 6, the fountain recycle."""
     cur = P.copy()
     scratch = np.zeros_like(cur)
+    L = lib()
+    L.sph_oracle_substep_fountain.restype = None
     for _ in range(steps):
-        lib().sph_oracle_substep(_ptr(cur), _ptr(scratch), len(cur), C.byref(p), dt)
+        if fountain is None:
+            L.sph_oracle_substep(_ptr(cur), _ptr(scratch), len(cur), C.byref(p), C.c_float(dt))
+        else:
+            L.sph_oracle_substep_fountain(_ptr(cur), _ptr(scratch), len(cur), C.byref(p), C.c_float(dt), C.byref(fountain))
     return cur
+
+
+def fountain_recycle(P: np.ndarray, p: OParams, f: OFountain, dt: float, seed: int) -> np.ndarray:
+    out = P.copy()
+    L = lib()
+    L.sph_oracle_fountain.restype = None
+    L.sph_oracle_fountain(_ptr(out), len(out), C.byref(p), C.byref(f), C.c_float(dt), C.c_uint32(seed))
+    return out
 
 
 def wave_impulse(P, amplitude, wavelength, phase, direction, y_min=-3.4028235e38, y_max=3.4028235e38):

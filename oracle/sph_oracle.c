@@ -875,6 +875,67 @@ static void o_pcg_seed(OPcg* r, uint64_t seed) {
     r->state = 0u; r->inc = (54u << 1u) | 1u;
     o_pcg_next(r); r->state += seed; o_pcg_next(r);
 }
+/* ====================================================================================
+ * Fountain recycle: DispatchCompute step 6 (SPHFluid3D.cpp:519, 526-544) and
+ * shaders/FountainRecycle.comp:24-54.  cos / sin are the pinned routines (5, 10).
+ * ==================================================================================== */
+typedef struct {
+    int32_t mode;                  /* fountainMode, SPHFluid3D.h:161 */
+    float offset[3];               /* fountainOffset :162 */
+    float radius, spread;          /* :163-164 */
+    float jetSpeedLive;            /* :165 */
+    float drainLevel, drainPerSec; /* :166-167 */
+    uint32_t seed;                 /* fountainSeed :168 */
+} OFountain;
+
+static inline float o_lcg(uint32_t* s) {                     /* FountainRecycle.comp:24-27 */
+    *s = *s * 1664525u + 1013904223u;
+    return (float)(*s & 0xFFFFFFu) / 16777215.0f;
+}
+
+void sph_oracle_fountain(OParticle* P, int n, const OParams* p, const OFountain* f, float dt, uint32_t seed) {
+    float half[3];
+    sph_oracle_effective_half(p, half);
+    const float emit[3] = { p->boxCenter[0] + f->offset[0], p->boxCenter[1] + f->offset[1], p->boxCenter[2] + f->offset[2] };
+    const float drainY = (p->boxCenter[1] - half[1]) + f->drainLevel;          /* :536-537 */
+    const float chance = fminf(1.0f, f->drainPerSec * dt);                     /* :538-539 */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* q = &P[i];
+        if (q->isGhost == 1) continue;                       /* :34 */
+        if (q->pos[1] >= drainY) continue;                   /* :35 */
+        uint32_t s = ((uint32_t)i ^ (seed * 747796405u)) + 2891336453u;
+        if (o_lcg(&s) > chance) continue;                    /* :38 */
+        float r1 = o_lcg(&s), r2 = o_lcg(&s), r3 = o_lcg(&s), r4 = o_lcg(&s);
+        float ang = 6.2831853f * r1;
+        float rad = f->radius * sqrtf(r2);
+        float ca = sph_oracle_cosf(ang), sa = sph_oracle_sinf(ang);
+        q->pos[0] = emit[0] + ca * rad;
+        q->pos[1] = emit[1] + 0.2f * r3;
+        q->pos[2] = emit[2] + sa * rad;
+        float sm = f->spread * r4;
+        float sx = ca * sm, sz = sa * sm;
+        float len = sqrtf(o_dot3(sx, 1.0f, sz, sx, 1.0f, sz));
+        q->vel[0] = f->jetSpeedLive * (sx / len);
+        q->vel[1] = f->jetSpeedLive * (1.0f / len);
+        q->vel[2] = f->jetSpeedLive * (sz / len);
+        q->acc[0] = q->acc[1] = q->acc[2] = q->acc[3] = 0.0f;
+        q->density = p->restDensity;
+        q->pressure = 0.0f;
+    }
+}
+
+/* DispatchCompute with the fountain step: f->seed advances per dispatch as fountainSeed++ (:541). */
+void sph_oracle_substep_fountain(OParticle* P, OParticle* scratch, int n, const OParams* p, float overrideDt, OFountain* f) {
+    if (p->pause) return;
+    sph_oracle_substep(P, scratch, n, p, overrideDt);
+    if (f && f->mode) {
+        const float dt = (overrideDt > 0.0f) ? overrideDt : p->timeStep;
+        sph_oracle_fountain(P, n, p, f, dt, f->seed);
+        f->seed = f->seed + 1u;
+    }
+}
+
 static float o_pcg_uniform(OPcg* r, float lo, float hi) {
     float u = (float)(o_pcg_next(r) >> 8) * (1.0f / 16777216.0f);
     return lo + u * (hi - lo);

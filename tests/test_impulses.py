@@ -167,3 +167,92 @@ def test_hip_impulses_bit_exact(pkg, oracle):
             want = oracle.substep(want, op)
         assert_records_equal(f.download(), want, f"impulses interleaved with substeps (lazy={lazy})")
         f.close()
+
+
+# ---- fountain recycle (DispatchCompute step 6) -------------------------------------------
+
+def _fountain_scene(pkg, n=6000):
+    sp = pkg.default_params(param_boxHalf=(3.0, 3.0, 3.0))
+    rec, mass = pkg.spawn_particles(sp, n, seed=21)
+    sp.param_mass = mass
+    rec["isGhost"][::37] = 1          # ghosts stay put (FountainRecycle.comp:34)
+    rec["isGhost"][5::41] = 2         # isGhost == 2 is NOT skipped by the fountain (== 1 test), but by OBB
+    rec["isActive"][3::29] = 0
+    return rec, sp
+
+
+def test_oracle_fountain_kat(oracle):
+    """FountainRecycle.comp:24-54 against a direct numpy statement (LCG stream, nozzle disc, jet cone)."""
+    n = 5000
+    rng = np.random.default_rng(8)
+    P = np.zeros(n, oracle.PARTICLE_DTYPE)
+    P["pos"][:, :3] = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    P["vel"][:, :3] = rng.normal(size=(n, 3)).astype(np.float32)
+    P["acc"][:, :3] = 1.0
+    P["density"], P["pressure"], P["isActive"] = 900.0, 5.0, 1
+    P["isGhost"][::10] = 1
+    P["padC"] = np.arange(n) % 3
+    p = oracle.default_params(boxHalf=(3, 3, 3), boxCenter=(0.5, 0.25, -0.5))
+    f = oracle.default_fountain(mode=1, offset=(0.0, -2.0, 0.0), drainPerSec=300.0, drainLevel=2.0)
+    dt, seed = 1e-3, 12345
+    out = oracle.fountain_recycle(P, p, f, dt, seed)
+    drain_y = np.float32(np.float32(0.25 - 3.0) + np.float32(2.0))
+    chance = np.float32(min(1.0, 300.0 * dt))
+    u32 = lambda v: np.uint32(v & 0xFFFFFFFF)
+    moved = 0
+    for i in range(n):
+        s = (int(i) ^ ((seed * 747796405) & 0xFFFFFFFF)) + 2891336453 & 0xFFFFFFFF
+        def lcg():
+            nonlocal s
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            return np.float32(np.float32(s & 0xFFFFFF) / np.float32(16777215.0))
+        rec = P[i]
+        expect_move = rec["isGhost"] != 1 and rec["pos"][1] < drain_y and lcg() <= chance
+        if not expect_move:
+            assert out[i].tobytes() == rec.tobytes(), i
+            continue
+        moved += 1
+        r1, r2, r3, r4 = lcg(), lcg(), lcg(), lcg()
+        ang = np.float64(np.float32(6.2831853) * r1)
+        rad = np.float64(np.sqrt(r2))
+        want = np.array([0.5 + np.cos(ang) * rad, 0.25 - 2.0 + 0.2 * r3, -0.5 + np.sin(ang) * rad])
+        np.testing.assert_allclose(out[i]["pos"][:3], want, atol=2e-6)
+        side = np.array([np.cos(ang), 1.0 / max(0.25 * r4, 1e-30), np.sin(ang)]) * (0.25 * r4)
+        side[1] = 1.0
+        v = 25.0 * side / np.linalg.norm(side)
+        np.testing.assert_allclose(out[i]["vel"][:3], v, rtol=2e-6, atol=2e-6)
+        assert np.all(out[i]["acc"] == 0) and out[i]["density"] == np.float32(1000.0) and out[i]["pressure"] == 0
+        assert out[i]["padC"] == rec["padC"] and out[i]["isActive"] == rec["isActive"]
+    assert 100 < moved < n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("neighbor,aos", [(0, 0), (1, 0), (0, 1)])
+def test_fountain_matches_oracle(pkg, oracle, neighbor, aos):
+    rec, sp = _fountain_scene(pkg)
+    f = pkg.SPHFluidGPU.from_particles(rec, sp)
+    f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)
+    f.set_option(pkg.SPH_OPT_AOS_MODE, aos)
+    f.fountainMode = 1
+    f.fountainOffset = (0.2, -2.5, -0.1)
+    f.fountainDrainPerSec = 150.0
+    f.fountainDrainLevel = 1.5
+    f.fountainSeed = 7
+    of = oracle.default_fountain(mode=1, offset=(0.2, -2.5, -0.1), drainPerSec=150.0, drainLevel=1.5, seed=7)
+    op = to_oracle_params(oracle, sp)
+    f.DispatchN(3)
+    want = oracle.substep(rec, op, steps=3, fountain=of)
+    assert f.fountainSeed == 10 == of.seed
+    f.fountainJetSpeedLive = 40.0                 # audio-kicked per frame in the reference (Scene0p.cpp:3560-3580)
+    of.jetSpeedLive = 40.0
+    for _ in range(3):
+        f.DispatchCompute(5e-4)
+    want = oracle.substep(want, op, dt=5e-4, steps=3, fountain=of)
+    got = f.download()
+    assert_records_equal(got, want, "fountain")
+    assert (got["density"] == np.float32(1000.0)).sum() > 20       # some particles really were recycled
+    f.fountainMode = 0
+    f.DispatchCompute()
+    assert f.fountainSeed == 13                   # no advance while the mode is off
+    assert_records_equal(f.download(), oracle.substep(want, op, steps=1), "fountain off")
+    f.close()
