@@ -69,7 +69,17 @@ struct SphEngine {
     uint32_t idBase = 0;
 
     // options
-    int optNeighbor = 0, optGridBuild = 0, optAos = 0, optTiming = 0;
+    int optNeighbor = 0, optGridBuild = 0, optAos = 0, optTiming = 0, optGraph = 0;
+    // hipGraph cache of sph_dispatch_n (SPH_OPT_GRAPH): one executable graph per distinct call
+    struct GraphEntry {
+        uint64_t key = 0;
+        hipGraphExec_t exec = nullptr;
+        int postCur = 0;
+        bool postAos = false, postAcc = false;
+        uint64_t lastUse = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graphClock = 0, graphLaunches = 0, graphCaptures = 0;
 
     // public contract buffer
     SphParticle* d_aos = nullptr;
@@ -160,6 +170,8 @@ void free_particle_buffers(SphEngine* e) {
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
     dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt); dev_free(e->d_shapeTab);
+    for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
     dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
     e->cap = 0;
 }
@@ -550,6 +562,7 @@ int sph_set_option(SphEngine* e, int option, int value) {
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
+    case SPH_OPT_GRAPH: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGraph = value; break;
     case SPH_OPT_DEBUG: e->tile.debugFlags = value; break;
     case SPH_OPT_TILE_CONFIG:
         if (value < 0 || value > 4) return fail(SPH_ERR_ARG, "bad value");
@@ -574,6 +587,8 @@ int sph_get_option(const SphEngine* e, int option, int* value) {
     case SPH_OPT_GRID_BUILD: *value = e->optGridBuild; break;
     case SPH_OPT_AOS_MODE: *value = e->optAos; break;
     case SPH_OPT_TIMING: *value = e->optTiming; break;
+    case SPH_OPT_GRAPH: *value = e->optGraph; break;
+    case SPH_OPT_GRAPH_LAUNCHES: *value = (int)e->graphLaunches; break;
     case SPH_OPT_DEBUG: *value = e->tile.debugFlags; break;
     case SPH_OPT_TILE_CONFIG: *value = e->tile.config; break;
     case SPH_OPT_TILE_X: *value = e->tile.tx; break;
@@ -588,11 +603,79 @@ int sph_dispatch(SphEngine* e, float overrideDt) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     return dispatch_one(e, overrideDt);
 }
+// Key of one sph_dispatch_n call for the graph cache: everything a captured launch sequence bakes in
+// (uniforms, options, buffer addresses, host-side validity state).
+static uint64_t graph_key(const SphEngine* e, float dt, int n) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t len) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < len; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    mix(&e->params, sizeof(e->params));
+    mix(&dt, sizeof(dt)); mix(&n, sizeof(n));
+    const int opts[10] = {e->optNeighbor, e->optGridBuild, e->optAos, e->tile.tx, e->tile.ty, e->tile.tz, e->tile.config, e->cur,
+                          (e->aosValid ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0), (int)e->idBase};
+    mix(opts, sizeof(opts));
+    const void* ptrs[8] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_cellStart, e->d_cellCount, e->d_order, e->d_llNext, e->d_shapeTab};
+    mix(ptrs, sizeof(ptrs));
+    const size_t sz[2] = {e->n, e->cap};
+    mix(sz, sizeof(sz));
+    return h ? h : 1;
+}
+
 int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
-    for (int i = 0; i < nSubsteps; ++i) {
-        int rc = dispatch_one(e, overrideDt);
-        if (rc) return rc;
+    // Scene0p runs up to 16 substeps per frame with unchanged members (Scene0p.cpp:1482-1494, :3720-3739);
+    // at the default 50 000 particles that loop is launch-bound, so the second identical call is
+    // captured into a hipGraph and replayed from then on.
+    const bool graphable = e->optGraph && nSubsteps >= 2 && !e->slab && !e->optTiming && !e->tile.debugFlags &&
+                           !e->fountain.fountainMode && !e->params.param_pause && e->n > 0;
+    SphEngine::GraphEntry* hit = nullptr;
+    uint64_t key = 0;
+    if (graphable) {
+        key = graph_key(e, overrideDt, nSubsteps);
+        for (auto& g : e->graphs) if (g.key == key) { hit = &g; break; }
+        if (hit && hit->exec) {
+            HIP_TRY(hipGraphLaunch(hit->exec, e->stream));
+            e->cur = hit->postCur; e->aosValid = hit->postAos; e->accValid = hit->postAcc; e->internalValid = true;
+            hit->lastUse = ++e->graphClock;
+            ++e->graphLaunches;
+            return SPH_OK;
+        }
+    }
+    const bool capture = graphable && hit;                   // seen once, run eagerly then: every buffer exists
+    if (capture) HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    int rc = SPH_OK;
+    for (int i = 0; i < nSubsteps && !rc; ++i) rc = dispatch_one(e, overrideDt);
+    if (capture) {
+        hipGraph_t graph = nullptr;
+        hipError_t er = hipStreamEndCapture(e->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (er != hipSuccess) return fail(SPH_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(er));
+        er = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (er != hipSuccess) { hit->exec = nullptr; return fail(SPH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(er)); }
+        hit->postCur = e->cur; hit->postAos = e->aosValid; hit->postAcc = e->accValid;
+        hit->lastUse = ++e->graphClock;
+        ++e->graphCaptures;
+        HIP_TRY(hipGraphLaunch(hit->exec, e->stream));
+        ++e->graphLaunches;
+        return SPH_OK;
+    }
+    if (rc) return rc;
+    if (graphable) {                                         // first sighting: remember it (at most 8 entries, LRU)
+        if (e->graphs.size() >= 8) {
+            size_t v = 0;
+            for (size_t i = 1; i < e->graphs.size(); ++i) if (e->graphs[i].lastUse < e->graphs[v].lastUse) v = i;
+            if (e->graphs[v].exec) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                (void)hipGraphExecDestroy(e->graphs[v].exec);
+            }
+            e->graphs.erase(e->graphs.begin() + (long)v);
+        }
+        SphEngine::GraphEntry g;
+        g.key = key; g.lastUse = ++e->graphClock;
+        e->graphs.push_back(g);
     }
     return SPH_OK;
 }

@@ -66,6 +66,7 @@ class SphGridInfo(C.Structure):
 
 # option / kernel-class constants of sph_abi.h
 SPH_OPT_NEIGHBOR_KERNEL, SPH_OPT_GRID_BUILD, SPH_OPT_AOS_MODE, SPH_OPT_TIMING, SPH_OPT_DEBUG = 1, 2, 3, 4, 100
+SPH_OPT_GRAPH, SPH_OPT_GRAPH_LAUNCHES = 5, 6
 KERNEL_CLASSES = ("bin", "scan", "scatter", "sph", "writeback", "impulse", "other")
 
 # every symbol include/sph_abi.h declares (checked by tests/test_abi.py)
@@ -347,6 +348,11 @@ class SPHFluidGPU:
     # -- engine extras -------------------------------------------------------------------
     def set_option(self, option: int, value: int):
         _check(self._L.sph_set_option(self._h, option, value))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int(0)
+        _check(self._L.sph_get_option(self._h, option, C.byref(v)))
+        return v.value
 
     def upload(self, particles: np.ndarray):
         arr = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)

@@ -114,6 +114,8 @@ enum {
     SPH_OPT_NEIGHBOR_KERNEL = 1, /* 0 = LDS-tiled 27-cell pass (default), 1 = per-particle global gather */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
+    SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
+    SPH_OPT_GRAPH_LAUNCHES = 6,  /* read-only: number of graph replays so far */
     SPH_OPT_TIMING = 4,          /* hipEvents around kernels for sph_kernel_times(): 1 = every kernel, 2 = only the SPH pass */
     /* test / tuning hooks */
     SPH_OPT_DEBUG = 100,         /* bit 0: force neighbour-list overflow, bit 1: force the sweep-3 re-scan, bit 2: force tile overflow,

@@ -352,3 +352,35 @@ def test_linked_list_variant_within_tolerance(pkg, oracle):
     f.DispatchCompute()
     assert np.isfinite(f.download()["pos"]).all()
     f.close()
+
+
+def test_dispatch_n_graph_replay(pkg, oracle):
+    """SPH_OPT_GRAPH: the Scene0p frame loop (16 substeps with unchanged members, Scene0p.cpp:1482-1494)
+    replayed as a hipGraph gives the same bits as eager dispatches; a member edit starts a new graph."""
+    f = pkg.SPHFluidGPU(20000, seed=3)
+    rec = f.download()
+    op = to_oracle_params(oracle, f.params)
+    f.set_option(pkg.SPH_OPT_GRAPH, 1)
+    for _ in range(6):                            # eager (state import), eager, capture + replay, replay, replay, replay
+        f.DispatchN(8)
+    assert f.get_option(pkg.SPH_OPT_GRAPH_LAUNCHES) == 4
+    want = oracle.substep(rec, op, steps=48)
+    assert_records_equal(f.download(), want, "graph replay 6 x 8")
+    f.ApplyWaveImpulse(1.0, 3.0, 0.5, (0, 1, 0))  # other calls may sit between frames
+    want = oracle.wave_impulse(want, 1.0, 3.0, 0.5, (0, 1, 0))
+    f.DispatchN(8)
+    assert f.get_option(pkg.SPH_OPT_GRAPH_LAUNCHES) == 5
+    want = oracle.substep(want, op, steps=8)
+    f.param_viscosity = 9.0                       # ImGui edit: new uniforms, new graph after two sightings
+    op.viscosity = 9.0
+    n0 = f.get_option(pkg.SPH_OPT_GRAPH_LAUNCHES)
+    for _ in range(5):
+        f.DispatchN(7)                            # odd count: the double buffer parity alternates between calls
+    assert f.get_option(pkg.SPH_OPT_GRAPH_LAUNCHES) > n0
+    want = oracle.substep(want, op, steps=35)
+    assert_records_equal(f.download(), want, "graph after member edit")
+    f.set_option(pkg.SPH_OPT_AOS_MODE, 1)
+    for _ in range(3):
+        f.DispatchN(4)
+    assert_records_equal(f.download(), oracle.substep(want, op, steps=12), "graph, lazy 80-byte array")
+    f.close()
