@@ -189,6 +189,21 @@ def main():
         except Exception:
             traffic = None
 
+    # The pass is VALU-bound, not HBM-bound: next to the contract's HBM roofline, price the
+    # measured VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/) against the issue peak of the chip
+    # (256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz).
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "r01_bench_pmc_sq.json")
+    if traffic is not None and os.path.exists(vpath) and sph_avg_s > 0:
+        try:
+            vj = json.load(open(vpath))
+            insts = next(v["SQ_INSTS_VALU"]["mean"] for k, v in vj.items() if "k_sph_tile" in k)
+            peak = 256 * 4 * 2.4e9 / 4.0
+            valu = {"wave_insts_per_launch": insts, "issue_peak_per_s": peak, "frac_of_issue_peak": insts / sph_avg_s / peak,
+                    "source": "profiles/r01_bench_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU, first 15 launches)"}
+        except Exception:
+            valu = None
+
     out = {
         "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-substeps/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -207,6 +222,7 @@ def main():
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },
         "kernels_us_per_substep": breakdown,
+        "valu": valu,
     }
     if not args.no_cpu_baseline and args.gpus == 1:
         out["cpu_baseline"] = cpu_baseline(pkg, rec, sp, args.cpu_steps)
