@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
-    ap.add_argument("--neighbor", type=int, default=0, help="0 LDS-tiled (default), 1 global gather")
+    ap.add_argument("--neighbor", type=int, default=0, help="0 LDS-tiled (default), 1 global gather, 2 gather over a sorted copy with LDS neighbour lists")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
     ap.add_argument("--tile-config", type=int, default=-1, help="LDS/workgroup shape of the tiled pass (engine default if < 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,12 +212,12 @@ def main():
             "workload": f"{wl}: {base.n} particles and a {gx}x{gy}x{gz}-cell grid per GPU (BASELINE.json configs[{base.index - 1}]"
                         + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")",
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
-            "neighbor_kernel": "lds_tile" if args.neighbor == 0 else "global_gather", "aos": args.aos,
+            "neighbor_kernel": ("lds_tile", "global_gather", "sorted_gather_lds_lists")[args.neighbor], "aos": args.aos,
             "pipeline": ("bin+scan+scatter+rank -> sph(27-cell, OBB + AoS update fused)" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB + AoS update fused)") + (" + halo exchange" if args.gpus > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else ("k_sph_tile" if args.neighbor == 0 else "k_sph_gather")),
+            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else ("k_sph_tile", "k_sph_gather", "k_sph_gather2")[args.neighbor]),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },

@@ -16,6 +16,13 @@
 #include "../../include/sph_abi.h"
 #include "sph_host.h"
 #include "sph_kernels.h"
+#include "sph_gather2.h"
+#ifndef SPH_G2_MAXN
+#define SPH_G2_MAXN 32
+#endif
+#ifndef SPH_G2_UNROLL
+#define SPH_G2_UNROLL 4
+#endif
 #include "sph_tile.h"
 
 static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
@@ -108,6 +115,8 @@ struct SphEngine {
     int z0 = 0, z1 = 0, hasLo = 0, hasHi = 0;
     size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count
     SphFountain fountain{};                 // fountain* members (SPHFluid3D.h:161-168)
+    float4 *d_sPos = nullptr, *d_sVel = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state (gather2 pass)
+    size_t sortedCap = 0;
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
     float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
     sph::ShapeTab shapeTab{};
@@ -169,7 +178,7 @@ void free_particle_buffers(SphEngine* e) {
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
-    dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt); dev_free(e->d_shapeTab);
+    dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt); dev_free(e->d_shapeTab); dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     e->graphs.clear();
     dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
@@ -258,6 +267,14 @@ int import_state(SphEngine* e) {
 int build_grid(SphEngine* e, const SimK& k) {
     const int n = (int)(e->slab ? e->nSlots : e->n), C = k.numCells;
     const int nb = blocks_for(n), sb = blocks_for((size_t)C, kScanTile);
+    const bool sortedCopy = e->optNeighbor == 2 && e->optGridBuild == 0;     // k_rank also writes the copy k_sph_gather2 reads
+    if (sortedCopy && (e->sortedCap < e->cap || !e->d_sPos)) {
+        int rc;
+        dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
+        e->d_sPos = e->d_sVel = e->d_sOwn = nullptr; e->sortedCap = 0;
+        if ((rc = dev_alloc(&e->d_sPos, e->cap)) || (rc = dev_alloc(&e->d_sVel, e->cap)) || (rc = dev_alloc(&e->d_sOwn, e->cap))) return rc;
+        e->sortedCap = e->cap;
+    }
     if (n) {
         Timed t(e, SPH_K_BIN);
         hipLaunchKernelGGL(k_bin, dim3(nb), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellCount, n);
@@ -271,7 +288,13 @@ int build_grid(SphEngine* e, const SimK& k) {
     if (n) {
         Timed t(e, SPH_K_SCATTER);
         hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n);
-        hipLaunchKernelGGL(k_rank, dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C);
+        if (sortedCopy) {
+            hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
+                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn);
+        } else {
+            hipLaunchKernelGGL((k_rank<false>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        }
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
@@ -357,7 +380,13 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     } else {
     if ((rc = build_grid(e, k))) return rc;                                 // :449-468
     if (n) {                                                                // :470-509 (SPH + OBB fused)
-        if (e->optNeighbor == 1) {
+        if (e->optNeighbor == 2) {
+            if (!e->d_sPos || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
+            const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
+            Timed t(e, SPH_K_SPH);
+            SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
+            hipLaunchKernelGGL((k_sph_gather2<SPH_G2_MAXN, SPH_G2_UNROLL>), dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, S, out, e->d_cellStart, live, n);
+        } else if (e->optNeighbor == 1) {
             Timed t(e, SPH_K_SPH);
             hipLaunchKernelGGL(k_sph_gather, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, e->d_order, e->d_cellStart, n);
         } else {
@@ -558,7 +587,7 @@ int sph_get_params(const SphEngine* e, SphParams* out) {
 int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
-    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optNeighbor = value; break;
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optNeighbor = value; break;
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
@@ -616,7 +645,7 @@ static uint64_t graph_key(const SphEngine* e, float dt, int n) {
     const int opts[10] = {e->optNeighbor, e->optGridBuild, e->optAos, e->tile.tx, e->tile.ty, e->tile.tz, e->tile.config, e->cur,
                           (e->aosValid ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0), (int)e->idBase};
     mix(opts, sizeof(opts));
-    const void* ptrs[8] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_cellStart, e->d_cellCount, e->d_order, e->d_llNext, e->d_shapeTab};
+    const void* ptrs[9] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_cellStart, e->d_cellCount, e->d_order, e->d_llNext, e->d_shapeTab, e->d_sPos};
     mix(ptrs, sizeof(ptrs));
     const size_t sz[2] = {e->n, e->cap};
     mix(sz, sizeof(sz));

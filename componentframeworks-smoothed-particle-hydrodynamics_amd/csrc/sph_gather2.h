@@ -1,0 +1,153 @@
+// k_sph_gather2: one thread per target over a physically SORTED copy of the entry state, with a
+// per-thread neighbour list kept in LDS.
+//
+// Why it exists next to the LDS-tiled pass (sph_tile.h): the tiled pass amortises staging and
+// per-cell candidate lists over the targets of a tile and wins while cells hold a few particles;
+// when the fluid is compressed (tens of particles per cell) its fixed-size lists, masks and tile
+// pools overflow into chunked / sub-box / slow paths.  This kernel has no such capacity: each
+// target walks the 9 contiguous (dy,dz) runs of its 27-cell neighbourhood once (density + list
+// of everything within h of its entry or of its predicted new position), then sweeps 2 and 3
+// touch only the listed neighbours.  The
+// list is private to the thread (column `tid` of an LDS array), so there is no barrier at all.
+// Arithmetic, candidate order and therefore the bits are those of sph_gather_one.
+#pragma once
+#include "sph_kernels.h"
+
+namespace sph {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct SortedIn {
+    const float4* __restrict__ posI;   // (x, y, z, 1/rho or 0)  in (cell, id) order of THIS substep
+    const float4* __restrict__ velP;   // (vx, vy, vz, P)
+    const float4* __restrict__ own;    // (rho, foam, bits(flags), bits(id))
+};   // written by k_rank<true>
+
+template <int MAXN, int UNROLL>
+__global__ __launch_bounds__(kBlock) void k_sph_gather2(SimK k, SortedIn S, StateOut out, const uint32_t* __restrict__ cellStart,
+                                                        const uint32_t* __restrict__ liveCount, int n) {
+    __shared__ uint16_t nl[MAXN][kBlock];      // entry e of thread t: (run << 12) | offset inside the run
+    __shared__ uint32_t runLo[9][kBlock];      // first sorted slot of each of the 9 runs
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * kBlock + tid;
+    const int bound = liveCount ? min(n, (int)*liveCount) : n;
+    if (s >= bound) return;
+    const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];
+    const uint32_t flags = fbits(O.z), id = fbits(O.w);
+    const float foamIn = O.y;
+    if (flags & F_HALO) { out.pos[s] = make_float4(P.x, P.y, P.z, O.z); return; }
+    Own o;
+    own_reset(o);
+    o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = O.x; o.prs = V.w;
+    if (flags & F_GHOST1) {                                  // SPHFluid.comp:72-83
+        if (!(flags & F_INACTIVE)) { o.vx = o.vy = o.vz = 0.0f; o.rho = k.rho0; o.prs = 0.0f; }
+        out.pos[s] = make_float4(P.x, P.y, P.z, O.z);
+        out.vel[s] = make_float4(o.vx, o.vy, o.vz, O.w);
+        out.rp[s] = make_float2(o.rho, o.prs);
+        out.foam[s] = foamIn;
+        if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
+        else out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
+    const int cy = cell_axis(P.y, k.gminy, k.cellSize, k.gy);
+    const int cz = cell_z_local(k, P.z);
+    const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
+    // The list must hold every candidate within h of the ENTRY position (sweep 2) and of the position
+    // after this substep's integration (sweep 3).  The latter is predicted as entry + 0.995 v dt; what
+    // the forces of this substep add to it is covered by eps and checked after integrate().
+    const float eps = 0.08f * k.h;
+    const float hp = k.h + eps;
+    const float hp2 = hp * hp;
+    const float qx = fmaf(0.995f * o.vx, k.dt, o.px), qy = fmaf(0.995f * o.vy, k.dt, o.py), qz = fmaf(0.995f * o.vz, k.dt, o.pz);
+    // ---- sweep 1: density over every candidate (branch-free: a rejected candidate adds +0), and the list ----
+    // all 18 run bounds first (independent loads in flight), then the runs in canonical order
+    uint32_t qs[9], qe[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+        const bool in = nz >= 0 && nz < k.gz && ny >= 0 && ny < k.gy;
+        const int rowBase = in ? (nz * k.gy + ny) * k.gx : 0;
+        const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
+        qs[r] = in ? a : 0u; qe[r] = in ? b : 0u;
+    }
+    int cnt = 0;
+    bool listOk = true;
+    // one candidate slot; an invalid slot (past the end of the run) is moved far away, so that it adds +0
+    // to the density and fails both list tests: the loop body has a single, rarely taken branch
+    // The two distances (to the entry and to the predicted position) are one packed-fp32 chain
+    // (v_pk_add / v_pk_mul / v_pk_fma_f32: two IEEE fp32 lanes per instruction, same rounding as dot3).
+    const v2f PX = {o.px, qx}, PY = {o.py, qy}, PZ = {o.pz, qz};
+    const v2f LIM = {k.h2hi, hp2};
+    auto visit = [&](const float4& J, bool valid, uint32_t q, uint32_t q0, int r) {
+        const float jx = valid ? J.x : 3.0e30f;
+        const v2f dx = PX - jx, dyy = PY - J.y, dzz = PZ - J.z;
+        const v2f d2 = __builtin_elementwise_fma(dzz, dzz, __builtin_elementwise_fma(dyy, dyy, dx * dx));   // (r2, p2)
+        const float tt = fmaxf(k.h2 - d2.x, 0.0f);
+        o.dens = fmaf(k.mass, k.poly6C * ((tt * tt) * tt), o.dens);
+        const v2f e = d2 - LIM;
+        if ((fminf(e.x, e.y) < 0.0f) & ((int)q != s)) {
+            nl[min(cnt, MAXN - 1)][tid] = (uint16_t)((r << 12) | (int)((q - q0) & 0xfffu));
+            ++cnt;
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t q0 = qs[r], q1 = qe[r];
+        runLo[r][tid] = q0;
+        if (q1 - q0 > 4096u) listOk = false;
+        for (uint32_t q = q0; q < q1; q += UNROLL) {
+            float4 J[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) J[u] = S.posI[min(q + (uint32_t)u, q1 - 1u)];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u, q0, r);
+        }
+    }
+    listOk = listOk && cnt <= MAXN;
+    finish_density(k, o);
+
+    // every candidate again, in canonical order (lists that did not fit, sweep 3 after a long move)
+    auto full = [&](auto&& f) {
+        for (int r = 0; r < 9; ++r) {
+            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+            if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
+            const int rowBase = (nz * k.gy + ny) * k.gx;
+            const uint32_t qs = cellStart[rowBase + xlo], qe = cellStart[rowBase + xhi + 1];
+            for (uint32_t q = qs; q < qe; ++q) {
+                if ((int)q == s) continue;
+                f(S.posI[q], S.velP[q]);
+            }
+        }
+    };
+    auto listed = [&](auto&& f) {
+        for (int e = 0; e < cnt; e += 4) {
+            float4 J[4], JV[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t a = nl[min(e + u, cnt - 1)][tid];
+                const uint32_t q = runLo[a >> 12][tid] + (a & 0xfffu);
+                J[u] = S.posI[q]; JV[u] = S.velP[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (e + u < cnt) f(J[u], JV[u]);
+        }
+    };
+    auto force_at = [&](const float4& J, const float4& JV) {
+        if (J.w > 0.0f) pair_force_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w);
+    };
+    auto xsph_at = [&](const float4& J, const float4& JV) {
+        if (J.w > 0.0f) pair_xsph_pre(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w);
+    };
+    // ---- sweep 2 ----
+    if (listOk) listed(force_at); else full(force_at);
+    integrate(k, o);
+    // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
+    const float mx = o.px - qx, my = o.py - qy, mz = o.pz - qz;
+    const float lim = 0.98f * eps;
+    if (listOk && dot3(mx, my, mz, mx, my, mz) <= lim * lim) listed(xsph_at); else full(xsph_at);
+    const float foamOut = finish_particle(k, o, foamIn);
+    store_particle(k, out, s, flags, id, o, foamOut);
+}
+
+}  // namespace sph

@@ -167,8 +167,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
 // ---- canonical order inside each cell: rank by ascending particle id ---------------------
 // (atomic arrival order in k_bin is arbitrary, exactly like BuildGrid.comp's atomicExchange;
 // this pass removes that freedom.)  order[s] = source index of the particle in sorted slot s.
+// With COPY the pass also writes the physically sorted copy of the entry state that k_sph_gather2
+// reads (sph_gather2.h SortedIn: 48 B per particle; 1/rho is the one correctly rounded division per
+// neighbour of the numerics contract, item 9).
+template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,
-                                                 const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells) {
+                                                 const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells,
+                                                 const float4* __restrict__ pos, const float4* __restrict__ vel,
+                                                 const float2* __restrict__ rp, const float* __restrict__ foam,
+                                                 float4* __restrict__ posI, float4* __restrict__ velP, float4* __restrict__ own) {
     int d = blockIdx.x * kBlock + threadIdx.x;
     if (d >= n || (uint32_t)d >= cellStart[numCells]) return;   // live particles only (cellStart[numCells] <= n)
     uint2 me = tmp[d];
@@ -177,6 +184,13 @@ __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, 
     uint32_t rank = 0;
     for (uint32_t q = s; q < e; ++q) rank += (tmp[q].x < me.x) ? 1u : 0u;
     order[s + rank] = me.y;
+    if (COPY) {
+        const float4 P = pos[me.y], V = vel[me.y];
+        const float2 RP = rp[me.y];
+        posI[s + rank] = make_float4(P.x, P.y, P.z, RP.x > 0.0f ? 1.0f / RP.x : 0.0f);
+        velP[s + rank] = make_float4(V.x, V.y, V.z, RP.y);
+        own[s + rank] = make_float4(RP.x, foam[me.y], P.w, V.w);
+    }
 }
 
 // ---- variant A: per-particle gather straight from global memory --------------------------

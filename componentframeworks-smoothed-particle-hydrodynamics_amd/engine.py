@@ -114,7 +114,8 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
             import torch  # noqa: F401
         except Exception:
             pass
-    L = C.CDLL(_build.LIB_PATH)
+    # developer A/B of kernel variants: SPH_HIP_LIB names another build of the same sources
+    L = C.CDLL(os.environ.get("SPH_HIP_LIB") or _build.LIB_PATH)
     vp, pp, gp = C.c_void_p, C.POINTER(SphParams), C.POINTER(SphGridInfo)
     f3 = C.POINTER(C.c_float)
     L.sph_abi_version.restype = C.c_int

@@ -13,7 +13,7 @@ from conftest import assert_records_equal, small_scene, to_oracle_params
 
 pytestmark = pytest.mark.gpu
 
-NEIGHBOR_VARIANTS = [("tile", 0), ("gather", 1)]
+NEIGHBOR_VARIANTS = [("tile", 0), ("gather", 1), ("gather2", 2)]
 
 
 def make_engine(pkg, rec, sp, neighbor=0, debug=0, tile=None, aos_lazy=False):
@@ -144,7 +144,7 @@ def test_container_shapes(pkg, oracle, shape):
     f.close()
 
 
-@pytest.mark.parametrize("neighbor,aos", [(1, 0), (0, 1)])
+@pytest.mark.parametrize("neighbor,aos", [(1, 0), (0, 1), (2, 0)])
 def test_ext_shape_other_paths(pkg, oracle, neighbor, aos):
     """A deferred-OBB shape through the gather kernel and with the lazy 80-byte array; the shape
     changes between dispatches (table re-upload), as the ImGui shape picker does (Scene0p.cpp:2380-2470)."""
@@ -272,7 +272,7 @@ def test_all_particles_in_one_cell(pkg, oracle):
     rec = np.zeros(3000, pkg.PARTICLE_DTYPE)
     rec["pos"][:, :3] = rng.uniform(0.01, 0.27, (3000, 3)).astype(np.float32)
     op = to_oracle_params(oracle, sp)
-    for neighbor in (0, 1):
+    for neighbor in (0, 1, 2):
         f = make_engine(pkg, rec, sp, neighbor)
         cnt, _ = f.download_grid()
         assert cnt.max() == 3000
@@ -289,12 +289,13 @@ def test_full_size_properties_config3(pkg):
     rec, _ = syn.make_particles(cfg)
     sp = pkg.default_params(**syn.params_fields(cfg))
     outs = []
-    for neighbor in (0, 1):
+    for neighbor in (0, 1, 2):
         f = make_engine(pkg, rec, sp, neighbor)
         f.DispatchN(3)
         outs.append(f.download())
         f.close()
     assert_records_equal(outs[0], outs[1], "tile vs gather at 4M")
+    assert_records_equal(outs[0], outs[2], "tile vs gather2 at 4M")
     out = outs[0]
     half = syn.box_half_for_grid(cfg.grid)
     assert np.all(np.abs(out["pos"][:, :3]) <= half[None, :] + 1e-4)
@@ -321,6 +322,20 @@ def test_dense_fluid_stays_on_the_tiled_path(pkg, oracle, scale):
     assert c["scangroups"] / max(c["waverounds"], 1) > 12          # the chunked path really ran
     if scale >= 0.6:
         assert c["slow_lanes"] == 0 and c["overflow_slices"] == 0
+    f.close()
+
+
+@pytest.mark.parametrize("scale", [0.75, 0.45, 0.3])
+def test_dense_fluid_gather2(pkg, oracle, scale):
+    """The sorted-gather pass on compressed fluid: neighbour lists beyond the 64 LDS entries per
+    thread (scale 0.45: ~11x, 0.3: ~37x the lattice density) fall back to full candidate sweeps."""
+    rec, sp = small_scene(pkg, n=4096, grid=16, seed=41)
+    op = to_oracle_params(oracle, sp)
+    P = oracle.substep(rec, op, steps=2)
+    P["pos"][:, :3] *= np.float32(scale)
+    f = make_engine(pkg, P, sp, 2)
+    f.DispatchN(3)
+    assert_records_equal(f.download(), oracle.substep(P, op, steps=3), f"gather2 scale {scale}")
     f.close()
 
 

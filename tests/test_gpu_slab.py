@@ -43,7 +43,7 @@ def _group(pkg, halo, P, sp, world, neighbor=0):
                                          lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), 8192, cz)
 
 
-@pytest.mark.parametrize("neighbor", [0, 1])
+@pytest.mark.parametrize("neighbor", [0, 1, 2])
 @pytest.mark.parametrize("world", [1, 2, 3, 5])
 def test_slabs_match_single_engine_and_oracle(pkg, oracle, world, neighbor):
     halo = importlib.import_module(PKG_NAME + ".halo")
