@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
-    ap.add_argument("--neighbor", type=int, default=0, help="0 LDS-tiled (default), 1 global gather, 2 gather over a sorted copy with LDS neighbour lists")
+    ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 sorted gather with LDS neighbour lists (engine default), 0 LDS-tiled, 1 plain global gather")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
     ap.add_argument("--tile-config", type=int, default=-1, help="LDS/workgroup shape of the tiled pass (engine default if < 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,7 +197,8 @@ def main():
     if traffic is not None and os.path.exists(vpath) and sph_avg_s > 0:
         try:
             vj = json.load(open(vpath))
-            insts = next(v["SQ_INSTS_VALU"]["mean"] for k, v in vj.items() if "k_sph_tile" in k)
+            kname = ("k_sph_tile", "k_sph_gather", "k_sph_gather2")[args.neighbor]
+            insts = next(v["SQ_INSTS_VALU"]["mean"] for k, v in vj.items() if kname + "<" in k or k.endswith(kname))
             peak = 256 * 4 * 2.4e9 / 4.0
             valu = {"wave_insts_per_launch": insts, "issue_peak_per_s": peak, "frac_of_issue_peak": insts / sph_avg_s / peak,
                     "source": "profiles/r01_bench_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU, first 15 launches)"}

@@ -76,7 +76,7 @@ struct SphEngine {
     uint32_t idBase = 0;
 
     // options
-    int optNeighbor = 0, optGridBuild = 0, optAos = 0, optTiming = 0, optGraph = 0;
+    int optNeighbor = 2, optGridBuild = 0, optAos = 0, optTiming = 0, optGraph = 0;
     // hipGraph cache of sph_dispatch_n (SPH_OPT_GRAPH): one executable graph per distinct call
     struct GraphEntry {
         uint64_t key = 0;

@@ -111,7 +111,7 @@ typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHF
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
 enum {
-    SPH_OPT_NEIGHBOR_KERNEL = 1, /* 0 = LDS-tiled 27-cell pass (default), 1 = per-particle global gather, 2 = per-particle gather over a sorted copy with LDS neighbour lists */
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = per-particle pass over a sorted copy with per-thread LDS neighbour lists (default), 0 = LDS-tiled 27-cell pass, 1 = plain per-particle global gather; all three give the same bits */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */

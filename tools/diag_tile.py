@@ -19,6 +19,7 @@ cfg = syn.CONFIGS[cfg_i]
 rec, _ = syn.make_particles(cfg)
 sp = pkg.default_params(**syn.params_fields(cfg))
 sim = pkg.SPHFluidGPU.from_particles(rec, sp)
+sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, 0)   # the stamps belong to the LDS-tiled pass
 sim.set_option(104, tcfg)
 if tile:
     for opt, v in zip((103, 102, 101), tile[::-1]):
