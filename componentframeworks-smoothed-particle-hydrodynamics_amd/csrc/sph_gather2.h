@@ -15,6 +15,15 @@
 
 namespace sph {
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+#ifndef SPH_G2_WAVES
+#define SPH_G2_WAVES 1
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct SortedIn {
@@ -23,31 +32,40 @@ struct SortedIn {
     const float4* __restrict__ own;    // (rho, foam, bits(flags), bits(id))
 };   // written by k_rank<true>
 
-template <int MAXN, int UNROLL>
-__global__ __launch_bounds__(kBlock) void k_sph_gather2(SimK k, SortedIn S, StateOut out, const uint32_t* __restrict__ cellStart,
+template <int MAXN, int UNROLL, int CAP>
+__global__ __launch_bounds__(kBlock, SPH_G2_WAVES) void k_sph_gather2(SimK k, SortedIn S, StateOut out, const uint32_t* __restrict__ cellStart,
                                                         const uint32_t* __restrict__ liveCount, int n) {
     __shared__ uint16_t nl[MAXN][kBlock];      // entry e of thread t: (run << 12) | offset inside the run
     __shared__ uint32_t runLo[9][kBlock];      // first sorted slot of each of the 9 runs
+    // CAP > 0: sweep 1 reads its candidates from a wave-private LDS window that the wave fills with
+    // coalesced loads (the 64 targets of a wave are consecutive sorted slots, so their 64 candidate
+    // ranges of one (dy,dz) row overlap heavily and their union is one short contiguous range).
+    __shared__ float4 stage[CAP > 0 ? kBlock / 64 : 1][CAP > 0 ? CAP : 1];
     const int tid = threadIdx.x;
-    const int s = blockIdx.x * kBlock + tid;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int sRaw = blockIdx.x * kBlock + tid;
     const int bound = liveCount ? min(n, (int)*liveCount) : n;
-    if (s >= bound) return;
+    // every lane stays in the kernel to the end (the staging is a wave-wide cooperation); lanes without
+    // a target to compute (past the end, halo copies, ghosts) get empty candidate ranges
+    bool live = sRaw < bound;
+    const int s = live ? sRaw : max(bound - 1, 0);
     const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];
     const uint32_t flags = fbits(O.z), id = fbits(O.w);
     const float foamIn = O.y;
-    if (flags & F_HALO) { out.pos[s] = make_float4(P.x, P.y, P.z, O.z); return; }
     Own o;
     own_reset(o);
     o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = O.x; o.prs = V.w;
-    if (flags & F_GHOST1) {                                  // SPHFluid.comp:72-83
-        if (!(flags & F_INACTIVE)) { o.vx = o.vy = o.vz = 0.0f; o.rho = k.rho0; o.prs = 0.0f; }
+    if (live && (flags & F_HALO)) { out.pos[s] = make_float4(P.x, P.y, P.z, O.z); live = false; }
+    if (live && (flags & F_GHOST1)) {                        // SPHFluid.comp:72-83
+        float gvx = o.vx, gvy = o.vy, gvz = o.vz, grho = o.rho, gprs = o.prs;
+        if (!(flags & F_INACTIVE)) { gvx = gvy = gvz = 0.0f; grho = k.rho0; gprs = 0.0f; }
         out.pos[s] = make_float4(P.x, P.y, P.z, O.z);
-        out.vel[s] = make_float4(o.vx, o.vy, o.vz, O.w);
-        out.rp[s] = make_float2(o.rho, o.prs);
+        out.vel[s] = make_float4(gvx, gvy, gvz, O.w);
+        out.rp[s] = make_float2(grho, gprs);
         out.foam[s] = foamIn;
         if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
         else out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        return;
+        live = false;
     }
     const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
     const int cy = cell_axis(P.y, k.gminy, k.cellSize, k.gy);
@@ -66,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_sph_gather2(SimK k, SortedIn S, Stat
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
-        const bool in = nz >= 0 && nz < k.gz && ny >= 0 && ny < k.gy;
+        const bool in = live && nz >= 0 && nz < k.gz && ny >= 0 && ny < k.gy;
         const int rowBase = in ? (nz * k.gy + ny) * k.gx : 0;
         const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
         qs[r] = in ? a : 0u; qe[r] = in ? b : 0u;
@@ -96,12 +114,36 @@ __global__ __launch_bounds__(kBlock) void k_sph_gather2(SimK k, SortedIn S, Stat
         const uint32_t q0 = qs[r], q1 = qe[r];
         runLo[r][tid] = q0;
         if (q1 - q0 > 4096u) listOk = false;
-        for (uint32_t q = q0; q < q1; q += UNROLL) {
-            float4 J[UNROLL];
+        bool staged = false;
+        uint32_t A = 0;
+        if (CAP > 0) {
+            // union of the wave's ranges of this row (empty ranges do not count)
+            A = wave_min_u32(q1 > q0 ? q0 : 0xffffffffu);
+            const uint32_t B = wave_max_u32(q1 > q0 ? q1 : 0u);
+            if (B <= A) continue;                              // nobody has a candidate in this row
+            staged = (B - A) <= (uint32_t)CAP;                 // wave-uniform
+            if (staged) {
+                for (uint32_t i = (uint32_t)lane; i < B - A; i += 64u) stage[wv][i] = S.posI[A + i];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (staged) {
+            for (uint32_t q = q0; q < q1; q += UNROLL) {
+                float4 J[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) J[u] = S.posI[min(q + (uint32_t)u, q1 - 1u)];
+                for (int u = 0; u < UNROLL; ++u) J[u] = stage[wv][min(q + (uint32_t)u, q1 - 1u) - A];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u, q0, r);
+                for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u, q0, r);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            for (uint32_t q = q0; q < q1; q += UNROLL) {
+                float4 J[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) J[u] = S.posI[min(q + (uint32_t)u, q1 - 1u)];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u, q0, r);
+            }
         }
     }
     listOk = listOk && cnt <= MAXN;
@@ -147,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_sph_gather2(SimK k, SortedIn S, Stat
     const float lim = 0.98f * eps;
     if (listOk && dot3(mx, my, mz, mx, my, mz) <= lim * lim) listed(xsph_at); else full(xsph_at);
     const float foamOut = finish_particle(k, o, foamIn);
-    store_particle(k, out, s, flags, id, o, foamOut);
+    if (live) store_particle(k, out, s, flags, id, o, foamOut);
 }
 
 }  // namespace sph
