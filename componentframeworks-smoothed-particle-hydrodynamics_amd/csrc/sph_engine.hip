@@ -25,7 +25,7 @@
 #define SPH_G2_CAP 128
 #endif
 #ifndef SPH_G2_UNROLL
-#define SPH_G2_UNROLL 4
+#define SPH_G2_UNROLL 3
 #endif
 #include "sph_tile.h"
 
@@ -389,7 +389,7 @@ int dispatch_one(SphEngine* e, float overrideDt) {
             const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
             Timed t(e, SPH_K_SPH);
             SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
-            hipLaunchKernelGGL((k_sph_gather2<SPH_G2_MAXN, SPH_G2_UNROLL, SPH_G2_CAP>), dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, S, out, e->d_cellStart, live, n);
+            hipLaunchKernelGGL((k_sph_gather2<SPH_G2_MAXN, SPH_G2_UNROLL, SPH_G2_CAP>), dim3(8 * ((blocks_for(n) + 7) / 8)), dim3(kBlock), 0, e->stream, k, S, out, e->d_cellStart, live, n);
         } else if (e->optNeighbor == 1) {
             Timed t(e, SPH_K_SPH);
             hipLaunchKernelGGL(k_sph_gather, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, e->d_order, e->d_cellStart, n);

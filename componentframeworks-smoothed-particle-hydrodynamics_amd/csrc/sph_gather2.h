@@ -43,7 +43,13 @@ __global__ __launch_bounds__(kBlock, SPH_G2_WAVES) void k_sph_gather2(SimK k, So
     __shared__ float4 stage[CAP > 0 ? kBlock / 64 : 1][CAP > 0 ? CAP : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int sRaw = blockIdx.x * kBlock + tid;
+    // XCD-aware block mapping: blocks b and b+8 run on the same XCD (round-robin dispatch); give each
+    // XCD one contiguous eighth of the sorted order, so that its L2 holds only that part of the sorted
+    // copy (plus the neighbouring rows) instead of streaming all of it.  Any mapping is correct.
+    const int nBlocks = (n + kBlock - 1) / kBlock, perXcd = (nBlocks + 7) >> 3;
+    const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
+    if (vb >= nBlocks) return;                               // whole block, uniformly
+    const int sRaw = vb * kBlock + tid;
     const int bound = liveCount ? min(n, (int)*liveCount) : n;
     // every lane stays in the kernel to the end (the staging is a wave-wide cooperation); lanes without
     // a target to compute (past the end, halo copies, ghosts) get empty candidate ranges
@@ -117,11 +123,18 @@ __global__ __launch_bounds__(kBlock, SPH_G2_WAVES) void k_sph_gather2(SimK k, So
         bool staged = false;
         uint32_t A = 0;
         if (CAP > 0) {
-            // union of the wave's ranges of this row (empty ranges do not count)
-            A = wave_min_u32(q1 > q0 ? q0 : 0xffffffffu);
-            const uint32_t B = wave_max_u32(q1 > q0 ? q1 : 0u);
-            if (B <= A) continue;                              // nobody has a candidate in this row
-            staged = (B - A) <= (uint32_t)CAP;                 // wave-uniform
+            // union of the wave's ranges of this row.  Lanes are consecutive sorted slots, so the row bases
+            // ascend with the lane: the union runs from the first non-empty lane's start to the last one's
+            // end (two readlanes instead of two wave reductions); checked below, with the direct loads as
+            // the fallback.
+            const bool ne = q1 > q0;
+            const unsigned long long mne = __ballot(ne);
+            if (mne == 0ull) continue;                         // nobody has a candidate in this row
+            const int lf = __ffsll((long long)mne) - 1, ll = 63 - __clzll((long long)mne);
+            A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
+            const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
+            const bool inside = !__any(ne && (q0 < A || q1 > B));
+            staged = inside && B > A && (B - A) <= (uint32_t)CAP;   // wave-uniform
             if (staged) {
                 for (uint32_t i = (uint32_t)lane; i < B - A; i += 64u) stage[wv][i] = S.posI[A + i];
                 __builtin_amdgcn_wave_barrier();
