@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""SPH-pass time of the tiled and the gather kernel along the trajectory of a bench workload
-(the kernels are bit-identical, so switching between them does not perturb the run).
-usage: regime_sweep.py [config index=3] [last step=300] [stride=25]"""
+"""SPH-pass time along the trajectory of a bench workload (the fluid column of configs[2] collapses,
+DESIGN.md section 6).  The passes are bit-identical, so switching between them does not perturb the run.
+usage: regime_sweep.py [config index=3] [last step=300] [stride=25] [passes, e.g. 2,0,1]
+pass ids: 2 sorted gather, 0 tiled (+ slow queue), 1 plain gather"""
 import importlib
 import json
 import os
@@ -15,32 +16,36 @@ syn = pkg.synthetic
 ci = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 stride = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+kinds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2,0,1").split(",")]
 cfg = syn.CONFIGS[ci]
 sp = pkg.default_params(**syn.params_fields(cfg))
 rec, _ = syn.make_particles(cfg)
 f = pkg.SPHFluidGPU.from_particles(rec, sp)
+REPS = 3
 
 
-def timed(neighbor, reps=3):
-    f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)
+def select(kind):
+    f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, kind)
+
+
+def timed(kind):
+    select(kind)
     f.set_option(pkg.SPH_OPT_TIMING, 1)
     f.kernel_times(reset=True)
-    f.DispatchN(reps)
+    f.DispatchN(REPS)
     kt = f.kernel_times(reset=True)
     f.set_option(pkg.SPH_OPT_TIMING, 0)
-    return {k: round(ms / reps * 1e3, 1) for k, (ms, c) in kt.items() if c}
+    return round(sum(ms for k, (ms, c) in kt.items() if k in ("sph", "other")) / REPS * 1e3, 1)
 
 
 step = 0
-rows = []
 while step <= last:
-    a = timed(0)
-    b = timed(1)
-    c = timed(2)
-    step += 9
-    g = f.download_grid() if False else None
-    rows.append({"step": step, "tile_sph_us": a.get("sph"), "tile_slow_us": a.get("other"), "gather_sph_us": b.get("sph"), "gather2_sph_us": c.get("sph"), "gather2_copy_us": round(c.get("scatter", 0) - a.get("scatter", 0), 1)})
-    print(json.dumps(rows[-1]), flush=True)
-    f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, 0)
-    f.DispatchN(max(0, stride - 9))
-    step += max(0, stride - 9)
+    row = {"step": step}
+    for kind in kinds:
+        row[{2: "gather2", 0: "tile+slow", 1: "gather"}[kind] + "_us"] = timed(kind)
+        step += REPS
+    print(json.dumps(row), flush=True)
+    select(2)
+    rest = max(0, stride - REPS * len(kinds))
+    f.DispatchN(rest)
+    step += rest
