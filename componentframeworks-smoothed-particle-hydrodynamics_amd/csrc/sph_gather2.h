@@ -21,6 +21,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
+#ifndef SPH_G2_LISTU
+#define SPH_G2_LISTU 4
+#endif
 #ifndef SPH_G2_WAVES
 #define SPH_G2_WAVES 1
 #endif
@@ -176,16 +179,16 @@ __global__ __launch_bounds__(kBlock, SPH_G2_WAVES) void k_sph_gather2(SimK k, So
         }
     };
     auto listed = [&](auto&& f) {
-        for (int e = 0; e < cnt; e += 4) {
-            float4 J[4], JV[4];
+        for (int e = 0; e < cnt; e += SPH_G2_LISTU) {
+            float4 J[SPH_G2_LISTU], JV[SPH_G2_LISTU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SPH_G2_LISTU; ++u) {
                 const uint32_t a = nl[min(e + u, cnt - 1)][tid];
                 const uint32_t q = runLo[a >> 12][tid] + (a & 0xfffu);
                 J[u] = S.posI[q]; JV[u] = S.velP[q];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (e + u < cnt) f(J[u], JV[u]);
+            for (int u = 0; u < SPH_G2_LISTU; ++u) if (e + u < cnt) f(J[u], JV[u]);
         }
     };
     auto force_at = [&](const float4& J, const float4& JV) {
