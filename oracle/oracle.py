@@ -77,8 +77,11 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        # SPH_ORACLE_LIB: another build of the same source (the Makefile's `ubsan` target) for a sanitizer run
+        alt = os.environ.get("SPH_ORACLE_LIB")
+        if not alt:
+            build()
+        L = C.CDLL(alt or _LIB_PATH)
         pp = C.POINTER(OParams)
         vp = C.c_void_p
         L.sph_oracle_sizeof_particle.restype = C.c_int
