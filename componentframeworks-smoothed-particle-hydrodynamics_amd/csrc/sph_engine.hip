@@ -235,13 +235,20 @@ int ensure_grid_buffers(SphEngine* e) {
     return SPH_OK;
 }
 
+constexpr long long kMaxCells = 1ll << 30;       // int32 cell indices and 4-byte-per-cell buffers stay far from overflow
+constexpr size_t kMaxParticles = (size_t)1 << 30;
 int validate_params(const SphParams& p) {
     if (!(p.param_h > 0.0f)) return fail(SPH_ERR_ARG, "param_h must be > 0");
+    SphGridInfo g;
+    compute_grid_extents(p, g);
+    const long long nc = (long long)g.dims[0] * g.dims[1] * g.dims[2];
+    if (nc > kMaxCells) return fail(SPH_ERR_CAPACITY, "grid of %d x %d x %d cells exceeds %lld cells (grid_cap %d)", g.dims[0], g.dims[1], g.dims[2], kMaxCells, p.grid_cap);
     return SPH_OK;
 }
 
 int set_particles(SphEngine* e, const SphParticle* host, size_t n) {
     int rc;
+    if (n > kMaxParticles) return fail(SPH_ERR_CAPACITY, "%zu particles exceed the engine limit of %zu", n, kMaxParticles);
     if (n > e->cap || !e->d_aos) { if ((rc = alloc_particle_buffers(e, n))) return rc; }
     e->n = n;
     e->hostInit.assign(host, host + n);

@@ -87,11 +87,12 @@ inline void compute_grid_extents(const SphParams& p, SphGridInfo& g) {
         float ext = std::fabs(R[i]) * half[0] + std::fabs(R[3 + i]) * half[1] + std::fabs(R[6 + i]) * half[2];
         ext = ext + g.cellSize;
         g.gridMin[i] = p.param_boxCenter[i] - ext;
-        int d = int(std::ceil((2.0f * ext) / g.cellSize));
-        g.dims[i] = d < 1 ? 1 : (d > cap ? cap : d);
+        // clamp in float, then convert (an out-of-range float -> int conversion is undefined)
+        const float df = std::ceil((2.0f * ext) / g.cellSize);
+        g.dims[i] = (df >= float(cap)) ? cap : ((df >= 1.0f) ? int(df) : 1);
     }
     const long long nc = (long long)g.dims[0] * g.dims[1] * g.dims[2];
-    g.numCells = nc < 1 ? 1 : (int)nc;
+    g.numCells = nc < 1 ? 1 : (nc > 2147483647LL ? 2147483647 : (int)nc);   // engines refuse grids beyond kMaxCells
 }
 
 // Per-dispatch constants (uniform derivation of SPHFluid3D.cpp:458-506, incl. maxSpeed :488).

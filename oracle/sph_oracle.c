@@ -198,13 +198,12 @@ void sph_oracle_grid_extents(const OParams* p, OGrid* g) {
         ext[i] = fabsf(R[i]) * half[0] + fabsf(R[3 + i]) * half[1] + fabsf(R[6 + i]) * half[2];
         ext[i] = ext[i] + g->cellSize;
         g->gridMin[i] = p->boxCenter[i] - ext[i];
-        int d = (int)ceilf((2.0f * ext[i]) / g->cellSize);
-        if (d < 1) d = 1;
-        if (d > p->gridCap) d = p->gridCap;
-        g->dims[i] = d;
+        /* clamp in float, then convert (an out-of-range float -> int conversion is undefined; semantic 8) */
+        const float df = ceilf((2.0f * ext[i]) / g->cellSize);
+        g->dims[i] = (df >= (float)p->gridCap) ? p->gridCap : ((df >= 1.0f) ? (int)df : 1);
     }
-    int nc = g->dims[0] * g->dims[1] * g->dims[2];
-    g->numCells = nc < 1 ? 1 : nc;
+    const long long nc = (long long)g->dims[0] * g->dims[1] * g->dims[2];
+    g->numCells = nc < 1 ? 1 : (nc > 2147483647LL ? 2147483647 : (int)nc);
 }
 
 /* BuildGrid.comp:21-31: cell coordinate of a position */

@@ -399,3 +399,28 @@ def test_dispatch_n_graph_replay(pkg, oracle):
         f.DispatchN(4)
     assert_records_equal(f.download(), oracle.substep(want, op, steps=12), "graph, lazy 80-byte array")
     f.close()
+
+
+def test_unreasonable_members_are_refused_not_faulted(pkg):
+    """Members a UI slider or a preset could produce must end in an error message, never in a device
+    fault: a grid beyond 2^30 cells (huge box with a raised grid_cap), a non-positive h, NaN extents."""
+    f = pkg.SPHFluidGPU(2000, seed=1)
+    f.DispatchCompute()
+    good = f.download()
+    f.grid_cap = 4000
+    f.param_boxHalf = (500.0, 500.0, 500.0)
+    with pytest.raises(pkg.SphError, match="cells"):
+        f.DispatchCompute()
+    f.param_boxHalf = (7.0, 7.0, 7.0)
+    f.param_h = 0.0
+    with pytest.raises(pkg.SphError, match="param_h"):
+        f.DispatchCompute()
+    f.param_h = 0.28
+    f.param_boxHalf = (float("nan"), 7.0, 7.0)            # NaN extents clamp to a 1-cell axis: runs, nothing faults
+    f.DispatchCompute()
+    f.param_boxHalf = (float("inf"), 7.0, 7.0)
+    f.grid_cap = 160
+    f.DispatchCompute()
+    f.sync()
+    assert len(f.download()) == len(good)
+    f.close()
