@@ -1,31 +1,28 @@
-// k_sph_gather2: one thread per target over a physically SORTED copy of the entry state, with a
-// per-thread neighbour list kept in LDS.
+// k_sph_gather2 (the default SPH pass): one thread per target over a physically SORTED copy of the
+// entry state, wave-cooperative LDS windows for the candidate scan and a per-thread neighbour list in LDS.
 //
-// Why it exists next to the LDS-tiled pass (sph_tile.h): the tiled pass amortises staging and
-// per-cell candidate lists over the targets of a tile and wins while cells hold a few particles;
-// when the fluid is compressed (tens of particles per cell) its fixed-size lists, masks and tile
-// pools overflow into chunked / sub-box / slow paths.  This kernel has no such capacity: each
-// target walks the 9 contiguous (dy,dz) runs of its 27-cell neighbourhood once (density + list
-// of everything within h of its entry or of its predicted new position), then sweeps 2 and 3
-// touch only the listed neighbours.  The
-// list is private to the thread (column `tid` of an LDS array), so there is no barrier at all.
-// Arithmetic, candidate order and therefore the bits are those of sph_gather_one.
+// Each target walks the 9 contiguous (dy,dz) rows of its 27-cell neighbourhood once (density + a list
+// of everything within h of its entry position or of its predicted new position), then sweeps 2 and 3
+// touch only the listed neighbours.  The list is private to the thread (column `tid` of an LDS array)
+// and the candidate windows are private to the wave, so the kernel has no __syncthreads at all.
+// Arithmetic, candidate order and therefore the bits are those of sph_gather_one (and of the oracle).
+//
+// Why it replaced the LDS-tiled pass (sph_tile.h) as the default: the tiled pass spends about a third
+// of a tile's cycles on staging and per-cell candidate lists for ~2 targets per cell, walks an
+// inflated-radius mask in sweeps 2/3, and its fixed-size lists, masks and tile pools overflow into
+// chunked / sub-box / slow paths when the fluid is compressed.  This kernel has no such capacity
+// limits (a long list or a long row only costs that thread / that wave a slower, exact fallback).
 #pragma once
 #include "sph_kernels.h"
 
 namespace sph {
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
-}
-
+// tuning knobs (values measured best on MI355X)
 #ifndef SPH_G2_LISTU
-#define SPH_G2_LISTU 4
+#define SPH_G2_LISTU 4      // list entries fetched together in sweeps 2 / 3
 #endif
 #ifndef SPH_G2_WAVES
-#define SPH_G2_WAVES 1
+#define SPH_G2_WAVES 1      // __launch_bounds__ minimum waves per SIMD (1 = let the register allocator decide)
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 
