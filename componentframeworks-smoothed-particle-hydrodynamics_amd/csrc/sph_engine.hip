@@ -19,10 +19,10 @@
 #include "sph_tile.h"
 #include "sph_gather2.h"
 #ifndef SPH_G2_MAXN
-#define SPH_G2_MAXN 24
+#define SPH_G2_MAXN 32
 #endif
 #ifndef SPH_G2_CAP
-#define SPH_G2_CAP 128
+#define SPH_G2_CAP 96
 #endif
 #ifndef SPH_G2_UNROLL
 #define SPH_G2_UNROLL 3
