@@ -186,6 +186,20 @@ def main():
         bt = sim.kernel_times(reset=True)
         sim.set_option(pkg.SPH_OPT_TIMING, 0)
         breakdown = {k: round(ms / nb * 1e3, 2) for k, (ms, cnt) in bt.items() if cnt}
+        if args.gpus == 1 and args.grid_build == "sort":
+            # untimed, for the record: the two other (bit-identical) SPH passes at the state the run has reached
+            alt = {}
+            for name, kind in (("sorted_gather_lds_lists", 2), ("lds_tile", 0), ("global_gather", 1)):
+                sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, kind)
+                sim.set_option(pkg.SPH_OPT_TIMING, 2)
+                sim.kernel_times(reset=True)
+                for _ in range(3):
+                    sim.DispatchCompute(dt)
+                ms, cnt = sim.kernel_times(reset=True)["sph"]
+                alt[name] = round(ms / max(cnt, 1) * 1e3, 1)
+            sim.set_option(pkg.SPH_OPT_TIMING, 0)
+            sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
+            breakdown["sph_pass_variants_after_run"] = alt
 
     if rank != 0:
         if dist is not None:
