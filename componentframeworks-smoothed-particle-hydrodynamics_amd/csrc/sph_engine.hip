@@ -849,6 +849,21 @@ int sph_device_particles(SphEngine* e, const SphParticle** devPtr) {
     return SPH_OK;
 }
 
+int sph_pack_render_buffer(SphEngine* e, float* devOut4, size_t n, int wMode) {
+    if (!e || (!devOut4 && n)) return fail(SPH_ERR_ARG, "null argument");
+    if (e->slab) return fail(SPH_ERR_STATE, "a slab engine has no local 80-byte array");
+    if (n != e->n) return fail(SPH_ERR_ARG, "size mismatch: %zu particles, engine has %zu", n, e->n);
+    if (wMode < 0 || wMode > 4) return fail(SPH_ERR_ARG, "bad w mode %d", wMode);
+    int rc;
+    if ((rc = writeback(e))) return rc;
+    if (n) {
+        Timed t(e, SPH_K_OTHER);
+        hipLaunchKernelGGL(k_pack_render, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, e->d_aos, reinterpret_cast<float4*>(devOut4), wMode, (int)n);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+
 int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n) {
     if (!e || (!host && n)) return fail(SPH_ERR_ARG, "null argument");
     if (n != e->hostInit.size()) return fail(SPH_ERR_ARG, "size mismatch");

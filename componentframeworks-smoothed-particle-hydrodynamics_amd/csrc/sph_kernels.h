@@ -324,6 +324,22 @@ __global__ __launch_bounds__(kBlock) void k_fountain(FountainK f, float4* __rest
     }
 }
 
+// Render-side export: what the reference's particle renderers read from the SSBO
+// (fluidDepth.vert / particleImpostor.vert: pos, padA foam, density, |vel|, padB dye), packed as one float4
+// per particle in ORIGINAL order, so that a renderer can map its vertex buffer once and never touch the
+// 80-byte records.  w: 0 = 1.0, 1 = density, 2 = foam (padA), 3 = speed, 4 = dye (padB).
+__global__ __launch_bounds__(kBlock) void k_pack_render(const SphParticle* __restrict__ aos, float4* __restrict__ out, int wMode, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* rec = reinterpret_cast<const float*>(aos + i);
+    float w = 1.0f;
+    if (wMode == 1) w = rec[12];
+    else if (wMode == 2) w = rec[14];
+    else if (wMode == 3) w = sqrtf(dot3(rec[4], rec[5], rec[6], rec[4], rec[5], rec[6]));
+    else if (wMode == 4) w = rec[15];
+    out[i] = make_float4(rec[0], rec[1], rec[2], w);
+}
+
 // SPHFluid.comp main() for the particle in sorted slot s, neighbours gathered from global
 // memory through order[] (variant A, and the exact fallback of the tiled kernel).
 __device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in, const StateOut& out,

@@ -76,7 +76,7 @@ ABI_SYMBOLS = (
     "sph_create_from_particles", "sph_destroy", "sph_reset", "sph_set_params", "sph_get_params",
     "sph_set_option", "sph_get_option", "sph_dispatch", "sph_dispatch_n", "sph_apply_wave_impulse",
     "sph_num_particles", "sph_grid_info", "sph_upload_particles", "sph_download_particles",
-    "sph_device_particles", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
+    "sph_device_particles", "sph_pack_render_buffer", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
     "sph_debug_counters", "sph_apply_vortex_impulse", "sph_apply_attractor_impulse", "sph_set_stencil_targets",
     "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
 )
@@ -142,6 +142,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_upload_particles.argtypes = [vp, vp, C.c_size_t]
     L.sph_download_particles.argtypes = [vp, vp, C.c_size_t]
     L.sph_device_particles.argtypes = [vp, C.POINTER(vp)]
+    L.sph_pack_render_buffer.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.sph_initial_particles.argtypes = [vp, vp, C.c_size_t]
     L.sph_download_grid.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
     L.sph_sync.argtypes = [vp]
@@ -370,6 +371,11 @@ class SPHFluidGPU:
         p = C.c_void_p()
         _check(self._L.sph_device_particles(self._h, C.byref(p)))
         return int(p.value)
+
+    def pack_render_buffer(self, dev_ptr: int, w_mode: int = 0):
+        """(x, y, z, w) per particle in original order into a caller-owned device buffer (a mapped vertex
+        buffer in a renderer; a torch tensor's data_ptr() in the tests)."""
+        _check(self._L.sph_pack_render_buffer(self._h, C.c_void_p(dev_ptr), self.GetNumFluids(), int(w_mode)))
 
     def download_grid(self):
         g = compute_grid_extents(self._p)

@@ -120,6 +120,9 @@ public:
         Check(sph_device_particles(engine, &p), "sph_device_particles");
         return reinterpret_cast<const SPHParticle*>(p);
     }
+    // packed (x, y, z, w) per particle in original order into a device buffer of the renderer (w: 0 one, 1 density,
+    // 2 foam, 3 speed, 4 dye): the render-side replacement of binding 0 reads (fluidDepth.vert, particleImpostor.vert)
+    void PackRenderBuffer(float* devOut4, int wMode = 0) { Check(sph_pack_render_buffer(engine, devOut4, sph_num_particles(engine), wMode), "sph_pack_render_buffer"); }
     bool Download(std::vector<SPHParticle>& out) {
         out.resize(sph_num_particles(engine));
         return !Check(sph_download_particles(engine, reinterpret_cast<SphParticle*>(out.data()), out.size()), "sph_download_particles");

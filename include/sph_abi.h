@@ -202,6 +202,12 @@ int sph_download_particles(SphEngine* e, SphParticle* host, size_t n);
 /* Device pointer of the 80-byte AoS in original order: the `ssbo` renderers bind
  * (Scene0p.cpp:1625,2627,3065,3142). Borrowed, read-only, invalidated by reset/destroy. */
 int sph_device_particles(SphEngine* e, const SphParticle** devPtr);
+/* Render-side export: one float4 (x, y, z, w) per particle in original order into a DEVICE buffer the
+ * caller owns (e.g. a GL vertex buffer mapped through HIP-GL interop), replacing the renderers' reads of
+ * binding 0 (shaders/fluidDepth.vert:16-24, particleImpostor.vert; Scene0p.cpp:1625,2627,3065).
+ * wMode: 0 = 1.0, 1 = density, 2 = foam (padA), 3 = speed |vel|, 4 = dye (padB).  Asynchronous on the
+ * engine's stream; n must equal sph_num_particles. */
+int sph_pack_render_buffer(SphEngine* e, float* devOut4, size_t n, int wMode);
 /* Initial host-side records (SPHFluidGPU::particles: initial state only, never refreshed). */
 int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n);
 /* Grid as BuildGrid.comp defines it, for tests: cellCount[numCells] and

@@ -424,3 +424,32 @@ def test_unreasonable_members_are_refused_not_faulted(pkg):
     f.sync()
     assert len(f.download()) == len(good)
     f.close()
+
+
+@pytest.mark.parametrize("aos", [0, 1])
+def test_pack_render_buffer(pkg, aos):
+    """sph_pack_render_buffer: the packed float4 a renderer would consume equals the 80-byte records."""
+    import torch
+    rec, sp = small_scene(pkg, n=2500, grid=14, seed=44)
+    rec["padB"] = np.linspace(0, 1, len(rec), dtype=np.float32)
+    f = make_engine(pkg, rec, sp)
+    f.set_option(pkg.SPH_OPT_AOS_MODE, aos)
+    f.DispatchN(4)
+    out = torch.zeros((len(rec), 4), dtype=torch.float32, device="cuda")
+    want = None
+    for mode in range(5):
+        f.pack_render_buffer(out.data_ptr(), mode)
+        f.sync()
+        got = out.cpu().numpy()
+        if want is None:
+            want = f.download()
+        w = {0: np.ones(len(rec), np.float32), 1: want["density"], 2: want["padA"], 4: want["padB"]}.get(mode)
+        assert np.array_equal(got[:, :3], want["pos"][:, :3])
+        if mode == 3:
+            v = want["vel"][:, :3].astype(np.float64)
+            np.testing.assert_allclose(got[:, 3], np.sqrt((v * v).sum(1)), rtol=1e-6)
+        else:
+            assert np.array_equal(got[:, 3], w)
+    with pytest.raises(pkg.SphError, match="size mismatch"):
+        pkg.engine._check(f._L.sph_pack_render_buffer(f._h, out.data_ptr(), len(rec) - 1, 0))
+    f.close()
