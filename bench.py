@@ -35,9 +35,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
-    ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 sorted gather with LDS neighbour lists (engine default), 0 LDS-tiled, 1 plain global gather")
+    ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 = k_sph_pair (engine default), 1 = k_sph_slow (plain per-target sweeps)")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
-    ap.add_argument("--tile-config", type=int, default=-1, help="LDS/workgroup shape of the tiled pass (engine default if < 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="substeps of the CPU sample (0 = auto, about 10-30 s)")
     ap.add_argument("--grid-build", default="sort", choices=["sort", "ll"], help="counting sort (default) or the reference's linked lists (A/B)")
@@ -134,8 +133,6 @@ def main():
         rec = None
         n_local, n_total = sim.num_owned(), cfg.n
     sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
-    if args.tile_config >= 0:
-        sim.set_option(104, args.tile_config)
     sim.set_option(pkg.SPH_OPT_AOS_MODE, 0 if args.aos == "eager" else 1)
     if args.grid_build == "ll":
         sim.set_option(pkg.SPH_OPT_GRID_BUILD, 1)
@@ -189,7 +186,7 @@ def main():
         if args.gpus == 1 and args.grid_build == "sort":
             # untimed, for the record: the two other (bit-identical) SPH passes at the state the run has reached
             alt = {}
-            for name, kind in (("sorted_gather_lds_lists", 2), ("lds_tile", 0), ("global_gather", 1)):
+            for name, kind in (("k_sph_pair", 2), ("k_sph_slow", 1)):
                 sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, kind)
                 sim.set_option(pkg.SPH_OPT_TIMING, 2)
                 sim.kernel_times(reset=True)
@@ -231,7 +228,7 @@ def main():
     if traffic is not None and os.path.exists(vpath) and sph_avg_s > 0:
         try:
             vj = json.load(open(vpath))
-            kname = ("k_sph_tile", "k_sph_gather", "k_sph_gather2")[args.neighbor]
+            kname = (None, "k_sph_slow", "k_sph_pair")[args.neighbor]
             insts = next(v["SQ_INSTS_VALU"]["mean"] for k, v in vj.items() if kname + "<" in k or k.endswith(kname))
             peak = 256 * 4 * 2.4e9 / 4.0
             valu = {"wave_insts_per_launch": insts, "issue_peak_per_s": peak, "frac_of_issue_peak": insts / sph_avg_s / peak,
@@ -248,12 +245,12 @@ def main():
                         + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")"
                         + ("" if backend == "nccl" else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]"),
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
-            "neighbor_kernel": ("lds_tile", "global_gather", "sorted_gather_lds_lists")[args.neighbor], "aos": args.aos,
+            "neighbor_kernel": (None, "k_sph_slow", "k_sph_pair")[args.neighbor], "aos": args.aos,
             "pipeline": ("bin+scan+scatter+rank -> sph(27-cell, OBB + AoS update fused)" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB + AoS update fused)") + (" + halo exchange" if args.gpus > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else ("k_sph_tile", "k_sph_gather", "k_sph_gather2")[args.neighbor]),
+            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_pair")[args.neighbor]),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },

@@ -18,10 +18,10 @@ namespace sph {
 struct SimK {
     // SPHFluid.comp uniforms + derived kernel coefficients (:42-64)
     float h, h2, poly6C, spikyC, viscC;
-    float h2hi;   // h2 * (1 + 1e-6): r2 >= h2hi implies sqrt(r2) >= h, a cheap superset filter for the force sweep
-    float mass, negMass, rho0, halfRho0, kgas, visc, negSigma;
+    float mp6;           // mass * poly6C (density = mp6 * sum (h2-r2)^3)
+    float mass, negHalfMass, rho0, halfRho0, invRho0, kgas, visc, negSigma;
     float gravx, gravy, gravz;
-    float dt, maxSpeed, foamGen, foamVelRefMax;
+    float dt, maxSpeed, maxSpeed2, foamGen, invFoamRef;
     // grid (BuildGrid.comp:14-19)
     float gminx, gminy, gminz, cellSize;
     int gx, gy, gz, numCells;   // LOCAL grid (a z-slab rank: its layers plus one ghost layer each side)
@@ -64,120 +64,168 @@ __device__ __forceinline__ int cell_z_local(const SimK& k, float pz) {
     return min(max(cell_z_global(k, pz) - k.zoff, 0), k.gz - 1);
 }
 
-// Own state of one particle while it runs through SPHFluid.comp main().
-struct Own {
-    float px, py, pz;       // position (entry, then integrated)
-    float vx, vy, vz;       // velocity
-    float rho, prs;         // density / pressure of THIS substep (:106-111)
-    float dens;             // sweep-1 accumulator
-    float fPx, fPy, fPz, fVx, fVy, fVz, gCx, gCy, gCz, lapC;   // sweep-2 accumulators
-    float xsx, xsy, xsz, norm;                                 // sweep-3 accumulators
-    float ax, ay, az;       // acceleration written to the record (:167)
+// ======================= SPHFluid.comp main(), per-particle / per-pair arithmetic =======================
+// Written once as templates over T = float (one target per thread: k_sph_slow, k_sph_ll, exact fallbacks)
+// and T = v2f (two targets per lane, one v_pk_*_f32 per operation: k_sph_pair).  Packed fp32 operations
+// round each half exactly like the scalar instruction, so both instantiations give the same bits.
+//
+// ARITHMETIC CONTRACT (shared with oracle/sph_oracle.c o_sph_one, DESIGN.md "Numerics"): the sums, the
+// candidate order and the accept tests are SPHFluid.comp's; a few quantities are formed differently so that
+// the per-pair work is add / mul / fma only:
+//   1/sqrt(x) = t_rsqrt(x): integer seed + three Newton steps (<= 1 ulp measured, GLSL allows 2 ULP);
+//   sqrt(x) = x * t_rsqrt(x);  1/x = t_rsqrt(x)^2 for the particle's own density and the XSPH norm;
+//   density = (mass*poly6C) * sum (h2 - r2)^3;  the XSPH quotient drops the poly6 coefficient;
+//   spikyGrad = (spikyC (h-r)^2 / r) * rij;  viscosity term (vj - vi) * ((m/rho_j) * lapW);
+//   `r < h` is tested as r2 < h2 and `length(v) > maxSpeed` as |v|^2 > maxSpeed^2.
+// All pair functions are branch-free: a rejected candidate is evaluated with 1/rho_j := 0 (or weight 0) and
+// adds exactly +-0, which never changes an accumulator (accumulators start at +0 and cannot reach -0).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef int32_t v2i __attribute__((ext_vector_type(2)));
+
+template <class T> struct VecOf;
+template <> struct VecOf<float> { typedef uint32_t U; typedef int32_t I; };
+template <> struct VecOf<v2f> { typedef v2u U; typedef v2i I; };
+
+template <class T> __device__ __forceinline__ T t_splat(float x);
+template <> __device__ __forceinline__ float t_splat<float>(float x) { return x; }
+template <> __device__ __forceinline__ v2f t_splat<v2f>(float x) { v2f r = {x, x}; return r; }
+template <class T> __device__ __forceinline__ T t_fma(T a, T b, T c) { return __builtin_elementwise_fma(a, b, c); }
+template <class T> __device__ __forceinline__ T t_max(T a, T b) { return __builtin_elementwise_max(a, b); }
+template <class T> __device__ __forceinline__ T t_dot3(T ax, T ay, T az, T bx, T by, T bz) { return t_fma(az, bz, t_fma(ay, by, ax * bx)); }
+// all-ones / all-zeros masks (per half for v2f)
+__device__ __forceinline__ int32_t t_lt(float a, float b) { return a < b ? -1 : 0; }
+__device__ __forceinline__ int32_t t_gt(float a, float b) { return a > b ? -1 : 0; }
+__device__ __forceinline__ v2i t_lt(v2f a, v2f b) { v2i r = {a.x < b.x ? -1 : 0, a.y < b.y ? -1 : 0}; return r; }
+__device__ __forceinline__ v2i t_gt(v2f a, v2f b) { v2i r = {a.x > b.x ? -1 : 0, a.y > b.y ? -1 : 0}; return r; }
+__device__ __forceinline__ float t_and(float x, int32_t m) { return __uint_as_float(__float_as_uint(x) & (uint32_t)m); }
+__device__ __forceinline__ v2f t_and(v2f x, v2i m) { v2f r = {t_and(x.x, m.x), t_and(x.y, m.y)}; return r; }
+__device__ __forceinline__ float t_sel(int32_t m, float a, float b) { return m ? a : b; }
+__device__ __forceinline__ v2f t_sel(v2i m, v2f a, v2f b) { v2f r = {m.x ? a.x : b.x, m.y ? a.y : b.y}; return r; }
+
+// 1/sqrt(x) for normal x > 0: same operations as sph_oracle_rsqrt.
+__device__ __forceinline__ float t_rsqrt(float x) {
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
+    const float xh = 0.5f * x;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) { const float t = y * y; const float e = fmaf(-xh, t, 0.5f); y = fmaf(y, e, y); }
+    return y;
+}
+__device__ __forceinline__ v2f t_rsqrt(v2f x) {
+    v2f y = {__uint_as_float(0x5f3759dfu - (__float_as_uint(x.x) >> 1)), __uint_as_float(0x5f3759dfu - (__float_as_uint(x.y) >> 1))};
+    const v2f xh = 0.5f * x;
+    const v2f half = {0.5f, 0.5f};
+#pragma unroll
+    for (int it = 0; it < 3; ++it) { const v2f t = y * y; const v2f e = t_fma(-xh, t, half); y = t_fma(y, e, y); }
+    return y;
+}
+#define SPH_TINY 1e-30f
+
+// Own state of one particle (T = float) or of the two particles of a lane (T = v2f).
+template <class T>
+struct OwnT {
+    T px, py, pz;       // position (entry, then integrated)
+    T vx, vy, vz;       // velocity
+    T rho, prs;         // density / pressure of THIS substep (:106-111)
+    T dsum;             // sweep-1 accumulator: sum of (h2 - r2)^3
+    T fPx, fPy, fPz, fVx, fVy, fVz, gCx, gCy, gCz, lapC;   // sweep-2 accumulators
+    T xsx, xsy, xsz, norm;                                 // sweep-3 accumulators
+    T ax, ay, az;       // acceleration written to the record (:167)
 };
+typedef OwnT<float> Own;
 
-// ---- sweep 1, SPHFluid.comp:90-106: density (self included) -------------------------
-__device__ __forceinline__ void pair_density(const SimK& k, Own& o, float jx, float jy, float jz) {
-    float dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
-    float r2 = dot3(dx, dy, dz, dx, dy, dz);
-    if (r2 < k.h2) {
-        float t = k.h2 - r2;
-        float w = k.poly6C * ((t * t) * t);
-        o.dens = fmaf(k.mass, w, o.dens);
-    }
-}
-__device__ __forceinline__ void finish_density(const SimK& k, Own& o) {
-    o.rho = fmaxf(o.dens, k.halfRho0);                      // :106
-    o.prs = fmaxf(k.kgas * (o.rho - k.rho0), 0.0f);         // :111
+template <class T>
+__device__ __forceinline__ void own_reset(OwnT<T>& o) {
+    const T z = t_splat<T>(0.0f);
+    o.dsum = z;
+    o.fPx = o.fPy = o.fPz = o.fVx = o.fVy = o.fVz = o.gCx = o.gCy = o.gCz = o.lapC = z;
+    o.xsx = o.xsy = o.xsz = o.norm = z;
+    o.ax = o.ay = o.az = z;
 }
 
-// ---- sweep 2, :113-155: pressure / viscosity / colour field (self skipped by caller) -
-// invRho = 1 / rho_j depends on the neighbour only, so callers may form it once per staged
-// neighbour instead of once per pair (same bits either way).  Reciprocal forms fixed by the
-// numerics contract: mass / rho_j = mass * invRho, x / (2 rho_j) = (x * 0.5) *
-// invRho, rij / r = rij * (1/r).
-__device__ __forceinline__ void pair_force_pre(const SimK& k, Own& o, float jx, float jy, float jz,
-                                               float jvx, float jvy, float jvz, float jprs, float invRho) {
-    float dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
-    float r = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-    if (r < k.h) {
-        float gx = 0.0f, gy = 0.0f, gz = 0.0f;              // spikyGrad :50-57
-        float hr = k.h - r;
-        if (r > 0.0f) {
-            float invr = 1.0f / r;
-            float s = k.spikyC * (hr * hr);
-            gx = s * (dx * invr); gy = s * (dy * invr); gz = s * (dz * invr);
-        }
-        float pterm = ((k.negMass * (o.prs + jprs)) * 0.5f) * invRho;
-        float mor = k.mass * invRho;
-        float lapW = k.viscC * hr;                          // viscLaplacian :58-64
-        o.fPx = fmaf(gx, pterm, o.fPx); o.fPy = fmaf(gy, pterm, o.fPy); o.fPz = fmaf(gz, pterm, o.fPz);
-        o.fVx = fmaf((jvx - o.vx) * mor, lapW, o.fVx);
-        o.fVy = fmaf((jvy - o.vy) * mor, lapW, o.fVy);
-        o.fVz = fmaf((jvz - o.vz) * mor, lapW, o.fVz);
-        o.gCx = fmaf(mor, gx, o.gCx); o.gCy = fmaf(mor, gy, o.gCy); o.gCz = fmaf(mor, gz, o.gCz);
-        o.lapC = fmaf(mor, lapW, o.lapC);
-    }
+// ---- sweep 1, SPHFluid.comp:90-106: density (self included); r2 >= h2 adds +0 ----------
+template <class T, class M>
+__device__ __forceinline__ void pair_density(const SimK& k, OwnT<T>& o, T jx, T jy, T jz, M ok) {
+    const T dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
+    const T r2 = t_dot3(dx, dy, dz, dx, dy, dz);
+    const T t = t_and(t_max(t_splat<T>(k.h2) - r2, t_splat<T>(0.0f)), ok);
+    o.dsum = t_fma(t * t, t, o.dsum);
 }
-__device__ __forceinline__ void pair_force(const SimK& k, Own& o, float jx, float jy, float jz,
-                                           float jvx, float jvy, float jvz, float jrho, float jprs) {
-    if (jrho > 0.0f) pair_force_pre(k, o, jx, jy, jz, jvx, jvy, jvz, jprs, 1.0f / jrho);
+template <class T>
+__device__ __forceinline__ void finish_density(const SimK& k, OwnT<T>& o) {
+    o.rho = t_max(k.mp6 * o.dsum, t_splat<T>(k.halfRho0));                       // :106
+    o.prs = t_max(k.kgas * (o.rho - t_splat<T>(k.rho0)), t_splat<T>(0.0f));     // :111
+}
+
+// ---- sweep 2, :113-155: pressure / viscosity / colour field.  `ok` = candidate is another particle of
+// the target's 27-cell stencil; invRho = 1 / rho_j (0 for rho_j <= 0), formed once per neighbour. ----------
+template <class T, class M>
+__device__ __forceinline__ void pair_force(const SimK& k, OwnT<T>& o, T jx, T jy, T jz, T jvx, T jvy, T jvz, T jprs, T invRho, M ok) {
+    const T dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
+    const T r2 = t_dot3(dx, dy, dz, dx, dy, dz);
+    const M acc = ok & t_lt(r2, t_splat<T>(k.h2)) & t_gt(invRho, t_splat<T>(0.0f));
+    const T ie = t_and(invRho, acc);
+    const T rinv = t_rsqrt(t_max(r2, t_splat<T>(SPH_TINY)));
+    const T r = r2 * rinv;
+    const T hr = t_splat<T>(k.h) - r;
+    const T sr = (k.spikyC * (hr * hr)) * rinv;             // spikyGrad :50-57 = sr * rij
+    const T gx = sr * dx, gy = sr * dy, gz = sr * dz;
+    const T mor = k.mass * ie;
+    const T pterm = ((o.prs + jprs) * k.negHalfMass) * ie;
+    const T ml = mor * (k.viscC * hr);                      // viscLaplacian :58-64 times m / rho_j
+    o.fPx = t_fma(gx, pterm, o.fPx); o.fPy = t_fma(gy, pterm, o.fPy); o.fPz = t_fma(gz, pterm, o.fPz);
+    o.fVx = t_fma(jvx - o.vx, ml, o.fVx); o.fVy = t_fma(jvy - o.vy, ml, o.fVy); o.fVz = t_fma(jvz - o.vz, ml, o.fVz);
+    o.gCx = t_fma(mor, gx, o.gCx); o.gCy = t_fma(mor, gy, o.gCy); o.gCz = t_fma(mor, gz, o.gCz);
+    o.lapC = o.lapC + ml;
 }
 
 // ---- :157-171: surface tension, gravity, integrate -----------------------------------
-__device__ __forceinline__ void integrate(const SimK& k, Own& o) {
-    float fSx = 0.0f, fSy = 0.0f, fSz = 0.0f;
-    float gl = sqrtf(dot3(o.gCx, o.gCy, o.gCz, o.gCx, o.gCy, o.gCz));
-    if (gl > 1e-6f) {
-        float sc = k.negSigma * o.lapC;
-        fSx = sc * (o.gCx / gl); fSy = sc * (o.gCy / gl); fSz = sc * (o.gCz / gl);
-    }
-    float t;
-    t = fmaf(k.visc, o.fVx, o.fPx); t = t + k.gravx * o.rho; t = t + fSx; o.ax = t / o.rho;
-    t = fmaf(k.visc, o.fVy, o.fPy); t = t + k.gravy * o.rho; t = t + fSy; o.ay = t / o.rho;
-    t = fmaf(k.visc, o.fVz, o.fPz); t = t + k.gravz * o.rho; t = t + fSz; o.az = t / o.rho;
-    o.vx = fmaf(o.ax, k.dt, o.vx) * 0.995f; o.vy = fmaf(o.ay, k.dt, o.vy) * 0.995f; o.vz = fmaf(o.az, k.dt, o.vz) * 0.995f;
-    o.px = fmaf(o.vx, k.dt, o.px); o.py = fmaf(o.vy, k.dt, o.py); o.pz = fmaf(o.vz, k.dt, o.pz);
+template <class T>
+__device__ __forceinline__ void integrate(const SimK& k, OwnT<T>& o) {
+    const T gl2 = t_dot3(o.gCx, o.gCy, o.gCz, o.gCx, o.gCy, o.gCz);
+    const T sc = t_and(((k.negSigma * o.lapC) * t_rsqrt(t_max(gl2, t_splat<T>(SPH_TINY)))), t_gt(gl2, t_splat<T>(1e-12f)));
+    const T fSx = sc * o.gCx, fSy = sc * o.gCy, fSz = sc * o.gCz;
+    const T rr = t_rsqrt(t_max(o.rho, t_splat<T>(SPH_TINY)));
+    const T invRhoI = rr * rr;
+    T t;
+    t = t_fma(t_splat<T>(k.visc), o.fVx, o.fPx); t = t + k.gravx * o.rho; t = t + fSx; o.ax = t * invRhoI;
+    t = t_fma(t_splat<T>(k.visc), o.fVy, o.fPy); t = t + k.gravy * o.rho; t = t + fSy; o.ay = t * invRhoI;
+    t = t_fma(t_splat<T>(k.visc), o.fVz, o.fPz); t = t + k.gravz * o.rho; t = t + fSz; o.az = t * invRhoI;
+    const T dt = t_splat<T>(k.dt);
+    o.vx = t_fma(o.ax, dt, o.vx) * 0.995f; o.vy = t_fma(o.ay, dt, o.vy) * 0.995f; o.vz = t_fma(o.az, dt, o.vz) * 0.995f;
+    o.px = t_fma(o.vx, dt, o.px); o.py = t_fma(o.vy, dt, o.py); o.pz = t_fma(o.vz, dt, o.pz);
 }
 
 // ---- sweep 3, :177-201: XSPH against the neighbours' ENTRY state ----------------------
-__device__ __forceinline__ void pair_xsph_pre(const SimK& k, Own& o, float jx, float jy, float jz,
-                                              float jvx, float jvy, float jvz, float invRho) {
-    float dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
-    float r2 = dot3(dx, dy, dz, dx, dy, dz);
-    if (r2 < k.h2) {
-        float t = k.h2 - r2;
-        float w = k.poly6C * ((t * t) * t);
-        float mor = k.mass * invRho;
-        o.xsx = fmaf((jvx - o.vx) * w, mor, o.xsx);
-        o.xsy = fmaf((jvy - o.vy) * w, mor, o.xsy);
-        o.xsz = fmaf((jvz - o.vz) * w, mor, o.xsz);
-        o.norm = o.norm + w;
-    }
-}
-__device__ __forceinline__ void pair_xsph(const SimK& k, Own& o, float jx, float jy, float jz,
-                                          float jvx, float jvy, float jvz, float jrho) {
-    if (jrho > 0.0f) pair_xsph_pre(k, o, jx, jy, jz, jvx, jvy, jvz, 1.0f / jrho);
+template <class T, class M>
+__device__ __forceinline__ void pair_xsph(const SimK& k, OwnT<T>& o, T jx, T jy, T jz, T jvx, T jvy, T jvz, T invRho, M ok) {
+    const T dx = o.px - jx, dy = o.py - jy, dz = o.pz - jz;
+    const T r2 = t_dot3(dx, dy, dz, dx, dy, dz);
+    const M acc = ok & t_gt(invRho, t_splat<T>(0.0f));
+    const T t = t_and(t_max(t_splat<T>(k.h2) - r2, t_splat<T>(0.0f)), acc);
+    const T w3 = (t * t) * t;
+    const T wm = w3 * (k.mass * invRho);
+    o.xsx = t_fma(jvx - o.vx, wm, o.xsx); o.xsy = t_fma(jvy - o.vy, wm, o.xsy); o.xsz = t_fma(jvz - o.vz, wm, o.xsz);
+    o.norm = o.norm + w3;
 }
 
 // ---- :200-217: XSPH blend, velocity cap, foam; returns the new padA -------------------
-__device__ __forceinline__ float finish_particle(const SimK& k, Own& o, float foamIn) {
-    if (o.norm > 0.0f) { o.xsx = o.xsx / o.norm; o.xsy = o.xsy / o.norm; o.xsz = o.xsz / o.norm; }
-    o.vx = fmaf(0.12f, o.xsx, o.vx); o.vy = fmaf(0.12f, o.xsy, o.vy); o.vz = fmaf(0.12f, o.xsz, o.vz);
-    float sp = sqrtf(dot3(o.vx, o.vy, o.vz, o.vx, o.vy, o.vz));
-    if (sp > k.maxSpeed) {
-        float f = k.maxSpeed / sp;
-        o.vx = o.vx * f; o.vy = o.vy * f; o.vz = o.vz * f;
-    }
-    float speed = sqrtf(dot3(o.vx, o.vy, o.vz, o.vx, o.vy, o.vz));
-    float aer = clampf((k.rho0 - o.rho) / k.rho0, 0.0f, 1.0f) * clampf(speed / k.foamVelRefMax, 0.0f, 1.0f);
-    return fmaxf(aer * k.foamGen, foamIn * 0.995f);
-}
-
-__device__ __forceinline__ void own_reset(Own& o) {
-    o.dens = 0.0f;
-    o.fPx = o.fPy = o.fPz = o.fVx = o.fVy = o.fVz = o.gCx = o.gCy = o.gCz = o.lapC = 0.0f;
-    o.xsx = o.xsy = o.xsz = o.norm = 0.0f;
-    o.ax = o.ay = o.az = 0.0f;
+template <class T>
+__device__ __forceinline__ T finish_particle(const SimK& k, OwnT<T>& o, T foamIn) {
+    const T nr = t_rsqrt(t_max(o.norm, t_splat<T>(SPH_TINY)));
+    const T ninv = t_sel(t_gt(o.norm, t_splat<T>(0.0f)), nr * nr, t_splat<T>(1.0f));   // norm == 0: the sums are 0 as well
+    o.xsx = o.xsx * ninv; o.xsy = o.xsy * ninv; o.xsz = o.xsz * ninv;
+    const T c = t_splat<T>(0.12f);
+    o.vx = t_fma(c, o.xsx, o.vx); o.vy = t_fma(c, o.xsy, o.vy); o.vz = t_fma(c, o.xsz, o.vz);
+    const T sp2 = t_dot3(o.vx, o.vy, o.vz, o.vx, o.vy, o.vz);
+    const T f = t_sel(t_gt(sp2, t_splat<T>(k.maxSpeed2)), k.maxSpeed * t_rsqrt(t_max(sp2, t_splat<T>(SPH_TINY))), t_splat<T>(1.0f));
+    o.vx = o.vx * f; o.vy = o.vy * f; o.vz = o.vz * f;
+    const T s2 = t_dot3(o.vx, o.vy, o.vz, o.vx, o.vy, o.vz);
+    const T speed = s2 * t_rsqrt(t_max(s2, t_splat<T>(SPH_TINY)));
+    const T one = t_splat<T>(1.0f), zero = t_splat<T>(0.0f);
+    const T a0 = __builtin_elementwise_min(t_max((t_splat<T>(k.rho0) - o.rho) * k.invRho0, zero), one);
+    const T a1 = __builtin_elementwise_min(t_max(speed * k.invFoamRef, zero), one);
+    return t_max((a0 * a1) * k.foamGen, foamIn * 0.995f);
 }
 
 // ---- OBBConstraints.comp ---------------------------------------------------------------

@@ -16,18 +16,7 @@
 #include "../../include/sph_abi.h"
 #include "sph_host.h"
 #include "sph_kernels.h"
-#include "sph_tile.h"
-#include "sph_gather2.h"
-#ifndef SPH_G2_MAXN
-#define SPH_G2_MAXN 32
-#endif
-#ifndef SPH_G2_CAP
-#define SPH_G2_CAP 96
-#endif
-#ifndef SPH_G2_UNROLL
-#define SPH_G2_UNROLL 3
-#endif
-#include "sph_tile.h"
+#include "sph_pair.h"
 
 static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
 
@@ -104,15 +93,12 @@ struct SphEngine {
     bool internalValid = false, aosValid = false, accValid = false;
     // grid / sort scratch
     uint32_t *d_cellOf = nullptr, *d_slotOf = nullptr, *d_order = nullptr;
-    uint32_t *d_slowSlots = nullptr, *d_slowCount = nullptr;   // exceptional targets of the tiled pass
     float4* d_stencil = nullptr;            // SetStencilTargets points (binding 5 of StencilAttract.comp)
     size_t stencilCount = 0;
     int32_t *d_llNext = nullptr, *d_llCell = nullptr, *d_llKey = nullptr;   // linked-list A/B variant (particleNext, particleCell, cellKey)
     uint2* d_tmp = nullptr;
     uint32_t *d_cellCount = nullptr, *d_cellStart = nullptr, *d_blockSums = nullptr;
     int32_t* d_dbg = nullptr;
-    unsigned long long* d_stamps = nullptr;   // diagnostic tile-kernel counters (SPH_OPT_DEBUG bit 3), one row per tile
-    int stampTiles = 0;
     size_t dbgCap = 0;
     // z-slab (multi-GPU) mode: this engine owns global cell layers [z0, z1) and keeps one ghost layer per side
     bool slab = false;
@@ -125,8 +111,8 @@ struct SphEngine {
     float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
     sph::ShapeTab shapeTab{};
     uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count
-    // tile scheduler scratch (sph_tile.h)
-    sph::TilePlan tile{};
+    int debugFlags = 0;
+    unsigned long long* d_stats = nullptr;   // k_sph_pair diagnostics (SPH_OPT_DEBUG bit 3), see sph_debug_counters
 
     std::vector<SphParticle> hostInit;   // SPHFluidGPU::particles: initial state only
 
@@ -182,7 +168,7 @@ void free_particle_buffers(SphEngine* e) {
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
-    dev_free(e->d_slowSlots); dev_free(e->d_slowCount); dev_free(e->d_slabCnt); dev_free(e->d_shapeTab); dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
+    dev_free(e->d_slabCnt); dev_free(e->d_shapeTab); dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     e->graphs.clear();
     dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
@@ -190,7 +176,6 @@ void free_particle_buffers(SphEngine* e) {
 }
 void free_grid_buffers(SphEngine* e) {
     dev_free(e->d_cellCount); dev_free(e->d_cellStart); dev_free(e->d_blockSums);
-    tile_free(e->tile);
     e->allocatedCells = 0;
 }
 
@@ -209,8 +194,6 @@ int alloc_particle_buffers(SphEngine* e, size_t n) {
     if ((rc = dev_alloc(&e->d_slotOf, n))) return rc;
     if ((rc = dev_alloc(&e->d_order, n))) return rc;
     if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
-    if ((rc = dev_alloc(&e->d_slowSlots, n))) return rc;
-    if ((rc = dev_alloc(&e->d_slowCount, 4))) return rc;
     if ((rc = dev_alloc(&e->d_slabCnt, 4))) return rc;
     e->cap = n;
     return SPH_OK;
@@ -241,6 +224,8 @@ int validate_params(const SphParams& p) {
     if (!(p.param_h > 0.0f)) return fail(SPH_ERR_ARG, "param_h must be > 0");
     SphGridInfo g;
     compute_grid_extents(p, g);
+    for (int a = 0; a < 3; ++a)
+        if (g.dims[a] > 1024) return fail(SPH_ERR_CAPACITY, "grid axis %d has %d cells; the engine packs cell coordinates in 10 bits per axis (max 1024)", a, g.dims[a]);
     const long long nc = (long long)g.dims[0] * g.dims[1] * g.dims[2];
     if (nc > kMaxCells) return fail(SPH_ERR_CAPACITY, "grid of %d x %d x %d cells exceeds %lld cells (grid_cap %d)", g.dims[0], g.dims[1], g.dims[2], kMaxCells, p.grid_cap);
     return SPH_OK;
@@ -278,7 +263,7 @@ int import_state(SphEngine* e) {
 int build_grid(SphEngine* e, const SimK& k) {
     const int n = (int)(e->slab ? e->nSlots : e->n), C = k.numCells;
     const int nb = blocks_for(n), sb = blocks_for((size_t)C, kScanTile);
-    const bool sortedCopy = e->optNeighbor == 2 && e->optGridBuild == 0;     // k_rank also writes the copy k_sph_gather2 reads
+    const bool sortedCopy = e->optGridBuild == 0;     // k_rank also writes the sorted copy the SPH pass reads
     if (sortedCopy && (e->sortedCap < e->cap || !e->d_sPos)) {
         int rc;
         dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
@@ -301,10 +286,10 @@ int build_grid(SphEngine* e, const SimK& k) {
         hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n);
         if (sortedCopy) {
             hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn);
+                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn, k.gx, k.gy);
         } else {
             hipLaunchKernelGGL((k_rank<false>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.gx, k.gy);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -391,29 +376,16 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     } else {
     if ((rc = build_grid(e, k))) return rc;                                 // :449-468
     if (n) {                                                                // :470-509 (SPH + OBB fused)
+        if (!e->d_sPos || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
+        const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
+        SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
+        Timed t(e, SPH_K_SPH);
         if (e->optNeighbor == 2) {
-            if (!e->d_sPos || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
-            const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
-            Timed t(e, SPH_K_SPH);
-            SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
-            hipLaunchKernelGGL((k_sph_gather2<SPH_G2_MAXN, SPH_G2_UNROLL, SPH_G2_CAP>), dim3(8 * ((blocks_for(n) + 7) / 8)), dim3(kBlock), 0, e->stream, k, S, out, e->d_cellStart, live, n);
-        } else if (e->optNeighbor == 1) {
-            Timed t(e, SPH_K_SPH);
-            hipLaunchKernelGGL(k_sph_gather, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, e->d_order, e->d_cellStart, n);
+            const int units = (n + 127) / 128;
+            hipLaunchKernelGGL((k_sph_pair<SPH_PAIR_LN, SPH_PAIR_WCAP>), dim3(8 * ((units + 7) / 8)), dim3(64), 0, e->stream, k, S, in, out,
+                               e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
         } else {
-            if (e->tile.debugFlags & 8) {
-                const int nt = tile_count(e->tile, k);
-                if (nt > e->stampTiles) {
-                    dev_free(e->d_stamps);
-                    if ((rc = dev_alloc(&e->d_stamps, (size_t)nt * sph::TS_COUNT))) return rc;
-                    e->stampTiles = nt;
-                    HIP_TRY(hipMemsetAsync(e->d_stamps, 0, sizeof(unsigned long long) * sph::TS_COUNT * (size_t)nt, e->stream));
-                }
-            }
-            SlowQueue sq{e->d_slowCount, e->d_slowSlots};
-            if ((rc = tile_launch(e->tile, e->stream, k, in, out, e->d_order, e->d_cellStart, sq, e->d_stamps, [&](int cls) { return Timed(e, cls); }))) {
-                return fail(SPH_ERR_HIP, "tiled SPH pass failed: %s", hipGetErrorString((hipError_t)(-rc)));
-            }
+            hipLaunchKernelGGL(k_sph_slow, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, n);
         }
     }
     }
@@ -560,7 +532,7 @@ int sph_destroy(SphEngine* e) {
     free_grid_buffers(e);
     dev_free(e->d_dbg);
     dev_free(e->d_stencil);
-    dev_free(e->d_stamps);
+    dev_free(e->d_stats);
     for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -598,24 +570,19 @@ int sph_get_params(const SphEngine* e, SphParams* out) {
 int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
-    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optNeighbor = value; break;
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 2) return fail(SPH_ERR_ARG, "SPH pass %d: 2 = k_sph_pair, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
     case SPH_OPT_GRAPH: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGraph = value; break;
-    case SPH_OPT_DEBUG: e->tile.debugFlags = value; break;
-    case SPH_OPT_TILE_CONFIG:
-        if (value < 0 || value > 4) return fail(SPH_ERR_ARG, "bad value");
-        e->tile.config = value; e->tile.tx = 8; e->tile.ty = (value == 4) ? 2 : 4; e->tile.tz = (value == 1) ? 3 : ((value >= 3) ? 2 : 4);
+    case SPH_OPT_DEBUG:
+        e->debugFlags = value;
+        if ((value & 8) && !e->d_stats) {
+            int rc;
+            if ((rc = dev_alloc(&e->d_stats, 8))) return rc;
+            HIP_TRY(hipMemsetAsync(e->d_stats, 0, 8 * sizeof(unsigned long long), e->stream));
+        }
         break;
-    case SPH_OPT_TILE_X: case SPH_OPT_TILE_Y: case SPH_OPT_TILE_Z: {
-        int tx = e->tile.tx, ty = e->tile.ty, tz = e->tile.tz;
-        (option == SPH_OPT_TILE_X ? tx : option == SPH_OPT_TILE_Y ? ty : tz) = value;
-        if (value < 1 || (ty + 2) * (tz + 2) > sph::kMaxRows || (tx + 2) * (ty + 2) * (tz + 2) > sph::kMaxHaloCells || tx * ty > sph::kMaxCells)
-            return fail(SPH_ERR_ARG, "tile %dx%dx%d exceeds the kernel's LDS tables", tx, ty, tz);
-        e->tile.tx = tx; e->tile.ty = ty; e->tile.tz = tz;
-        break;
-    }
     default: return fail(SPH_ERR_ARG, "unknown option %d", option);
     }
     return SPH_OK;
@@ -629,11 +596,7 @@ int sph_get_option(const SphEngine* e, int option, int* value) {
     case SPH_OPT_TIMING: *value = e->optTiming; break;
     case SPH_OPT_GRAPH: *value = e->optGraph; break;
     case SPH_OPT_GRAPH_LAUNCHES: *value = (int)e->graphLaunches; break;
-    case SPH_OPT_DEBUG: *value = e->tile.debugFlags; break;
-    case SPH_OPT_TILE_CONFIG: *value = e->tile.config; break;
-    case SPH_OPT_TILE_X: *value = e->tile.tx; break;
-    case SPH_OPT_TILE_Y: *value = e->tile.ty; break;
-    case SPH_OPT_TILE_Z: *value = e->tile.tz; break;
+    case SPH_OPT_DEBUG: *value = e->debugFlags; break;
     default: return fail(SPH_ERR_ARG, "unknown option %d", option);
     }
     return SPH_OK;
@@ -653,7 +616,7 @@ static uint64_t graph_key(const SphEngine* e, float dt, int n) {
     };
     mix(&e->params, sizeof(e->params));
     mix(&dt, sizeof(dt)); mix(&n, sizeof(n));
-    const int opts[10] = {e->optNeighbor, e->optGridBuild, e->optAos, e->tile.tx, e->tile.ty, e->tile.tz, e->tile.config, e->cur,
+    const int opts[10] = {e->optNeighbor, e->optGridBuild, e->optAos, 0, 0, 0, 0, e->cur,
                           (e->aosValid ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0), (int)e->idBase};
     mix(opts, sizeof(opts));
     const void* ptrs[9] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_cellStart, e->d_cellCount, e->d_order, e->d_llNext, e->d_shapeTab, e->d_sPos};
@@ -668,7 +631,7 @@ int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps) {
     // Scene0p runs up to 16 substeps per frame with unchanged members (Scene0p.cpp:1482-1494, :3720-3739);
     // at the default 50 000 particles that loop is launch-bound, so the second identical call is
     // captured into a hipGraph and replayed from then on.
-    const bool graphable = e->optGraph && nSubsteps >= 2 && !e->slab && !e->optTiming && !e->tile.debugFlags &&
+    const bool graphable = e->optGraph && nSubsteps >= 2 && !e->slab && !e->optTiming && !e->debugFlags &&
                            !e->fountain.fountainMode && !e->params.param_pause && e->n > 0;
     SphEngine::GraphEntry* hit = nullptr;
     uint64_t key = 0;
@@ -899,15 +862,14 @@ int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* 
 
 int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset) {
     if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
-    if (count > (int)sph::TS_COUNT) count = (int)sph::TS_COUNT;
+    if (count > 8) count = 8;
     for (int i = 0; i < count; ++i) out[i] = 0;
-    if (!e->d_stamps || e->stampTiles == 0) return SPH_OK;
+    if (!e->d_stats) return SPH_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    std::vector<unsigned long long> host((size_t)e->stampTiles * sph::TS_COUNT);
-    HIP_TRY(hipMemcpy(host.data(), e->d_stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int t = 0; t < e->stampTiles; ++t)
-        for (int i = 0; i < count; ++i) out[i] += host[(size_t)t * sph::TS_COUNT + i];
-    if (reset) HIP_TRY(hipMemset(e->d_stamps, 0, host.size() * sizeof(unsigned long long)));
+    unsigned long long host[8];
+    HIP_TRY(hipMemcpy(host, e->d_stats, sizeof(host), hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i) out[i] = host[i];
+    if (reset) HIP_TRY(hipMemset(e->d_stats, 0, sizeof(host)));
     return SPH_OK;
 }
 

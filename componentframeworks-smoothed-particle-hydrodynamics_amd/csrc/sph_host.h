@@ -100,18 +100,20 @@ inline void make_simk(const SphParams& p, const SphGridInfo& g, float dt, SimK& 
     const float h = p.param_h;
     const float h2 = h * h, h3 = h2 * h, h6 = h3 * h3, h9 = h6 * h3;
     const float pi_f = 3.141592653589f;               // literal of SPHFluid.comp:45,53,60
-    k.h = h; k.h2 = h2; k.h2hi = h2 * 1.000001f;
+    k.h = h; k.h2 = h2;
     k.poly6C = 315.0f / ((64.0f * pi_f) * h9);
     k.spikyC = -45.0f / (pi_f * h6);
     k.viscC = 45.0f / (pi_f * h6);
-    k.mass = p.param_mass; k.negMass = -p.param_mass;
-    k.rho0 = p.param_restDensity; k.halfRho0 = p.param_restDensity * 0.5f;
+    k.mass = p.param_mass; k.negHalfMass = (-p.param_mass) * 0.5f;
+    k.mp6 = p.param_mass * k.poly6C;
+    k.rho0 = p.param_restDensity; k.halfRho0 = p.param_restDensity * 0.5f; k.invRho0 = 1.0f / p.param_restDensity;
     k.kgas = p.param_gasConstant; k.visc = p.param_viscosity; k.negSigma = -p.param_surfaceTension;
     k.gravx = p.param_gravityX; k.gravy = p.param_gravityY; k.gravz = p.param_gravityZ;
     k.dt = dt;
     k.maxSpeed = (0.4f * h) / std::fmax(dt, 1e-6f);
+    k.maxSpeed2 = k.maxSpeed * k.maxSpeed;
     k.foamGen = p.param_foamGen;
-    k.foamVelRefMax = std::fmax(p.param_foamVelRef, 1e-3f);
+    k.invFoamRef = 1.0f / std::fmax(p.param_foamVelRef, 1e-3f);
     k.gminx = g.gridMin[0]; k.gminy = g.gridMin[1]; k.gminz = g.gridMin[2];
     k.cellSize = g.cellSize;
     k.gx = g.dims[0]; k.gy = g.dims[1]; k.gz = g.dims[2]; k.numCells = g.numCells;

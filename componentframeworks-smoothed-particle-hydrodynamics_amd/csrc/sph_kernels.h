@@ -5,7 +5,7 @@
 //   k_scan_*   exclusive scan of the histogram, clears it for the next substep (ClearGrid.comp)
 //   k_scatter  counting-sort scatter into cell-contiguous slots (replaces cellHead/particleNext)
 //   k_rank     canonical order inside a cell: ascending particle id (makes fp32 sums reproducible)
-//   k_sph_*    27-cell density -> pressure -> forces -> integrate -> XSPH -> cap -> foam, with
+//   k_sph_*    (sph_pair.h) 27-cell density -> pressure -> forces -> integrate -> XSPH -> cap -> foam, with
 //              OBBConstraints.comp fused into the epilogue (legal: neighbours are read from the
 //              entry snapshot, the own record is private to the thread)
 //   k_writeback  update of the public 80-byte AoS in ORIGINAL particle order
@@ -167,15 +167,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
 // ---- canonical order inside each cell: rank by ascending particle id ---------------------
 // (atomic arrival order in k_bin is arbitrary, exactly like BuildGrid.comp's atomicExchange;
 // this pass removes that freedom.)  order[s] = source index of the particle in sorted slot s.
-// With COPY the pass also writes the physically sorted copy of the entry state that k_sph_gather2
-// reads (sph_gather2.h SortedIn: 48 B per particle; 1/rho is the one correctly rounded division per
+// With COPY the pass also writes the physically sorted copy of the entry state that the SPH pass
+// reads (sph_pair.h SortedIn: 48 B per particle; 1/rho is the one correctly rounded division per
 // neighbour of the numerics contract, item 9).
 template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,
                                                  const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells,
                                                  const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                  const float2* __restrict__ rp, const float* __restrict__ foam,
-                                                 float4* __restrict__ posI, float4* __restrict__ velP, float4* __restrict__ own) {
+                                                 float4* __restrict__ posI, float4* __restrict__ velP, float4* __restrict__ own, int gx, int gy) {
     int d = blockIdx.x * kBlock + threadIdx.x;
     if (d >= n || (uint32_t)d >= cellStart[numCells]) return;   // live particles only (cellStart[numCells] <= n)
     uint2 me = tmp[d];
@@ -189,28 +189,9 @@ __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, 
         const float2 RP = rp[me.y];
         posI[s + rank] = make_float4(P.x, P.y, P.z, RP.x > 0.0f ? 1.0f / RP.x : 0.0f);
         velP[s + rank] = make_float4(V.x, V.y, V.z, RP.y);
-        own[s + rank] = make_float4(RP.x, foam[me.y], P.w, V.w);
-    }
-}
-
-// ---- variant A: per-particle gather straight from global memory --------------------------
-// One thread per sorted slot.  Neighbour cells are visited in ascending cell index
-// (dz outer, dy, dx inner); the three cells of one (dz,dy) row are contiguous in the sorted
-// order, so each row is ONE contiguous candidate range.
-template <class F>
-__device__ __forceinline__ void for_each_candidate(const SimK& k, int cx, int cy, int cz,
-                                                   const uint32_t* __restrict__ cellStart, F&& f) {
-    const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int nz = cz + dz;
-        if (nz < 0 || nz >= k.gz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int ny = cy + dy;
-            if (ny < 0 || ny >= k.gy) continue;
-            const int rowBase = (nz * k.gy + ny) * k.gx;
-            const uint32_t qs = cellStart[rowBase + xlo], qe = cellStart[rowBase + xhi + 1];
-            for (uint32_t q = qs; q < qe; ++q) f(q);
-        }
+        const uint32_t cxy = c % (uint32_t)(gx * gy);
+        const uint32_t cellBits = (cxy % (uint32_t)gx) | ((cxy / (uint32_t)gx) << 10) | ((c / (uint32_t)(gx * gy)) << 20);   // dims <= 1024 (validate_params)
+        own[s + rank] = make_float4(bitsf(cellBits), foam[me.y], P.w, V.w);
     }
 }
 
@@ -248,18 +229,6 @@ __device__ __forceinline__ void aos_write_active_ghost(SphParticle* __restrict__
     *reinterpret_cast<float4*>(rec + 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     *reinterpret_cast<float4*>(rec + 8) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     rec[12] = rho0; rec[13] = 0.0f;
-}
-
-// Ghost branch of SPHFluid.comp:72-83 and the common epilogue (OBB + store).
-__device__ __forceinline__ void store_particle(const SimK& k, const StateOut& out, int s, uint32_t flags, uint32_t id,
-                                               Own& o, float foamOut) {
-    if (!(flags & F_GHOSTNZ)) obb_apply(k, o.px, o.py, o.pz, o.vx, o.vy, o.vz);   // OBBConstraints.comp:46
-    out.pos[s] = make_float4(o.px, o.py, o.pz, bitsf(flags));
-    out.vel[s] = make_float4(o.vx, o.vy, o.vz, bitsf(id));
-    out.rp[s] = make_float2(o.rho, o.prs);
-    out.foam[s] = foamOut;
-    if (out.aos) aos_write_fluid(out.aos, id - out.idBase, o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
-    else out.acc[s] = make_float4(o.ax, o.ay, o.az, 0.0f);
 }
 
 // OBBConstraints.comp for container shapes 7..14, applied to the SPH pass's output state
@@ -338,64 +307,6 @@ __global__ __launch_bounds__(kBlock) void k_pack_render(const SphParticle* __res
     else if (wMode == 3) w = sqrtf(dot3(rec[4], rec[5], rec[6], rec[4], rec[5], rec[6]));
     else if (wMode == 4) w = rec[15];
     out[i] = make_float4(rec[0], rec[1], rec[2], w);
-}
-
-// SPHFluid.comp main() for the particle in sorted slot s, neighbours gathered from global
-// memory through order[] (variant A, and the exact fallback of the tiled kernel).
-__device__ __forceinline__ void sph_gather_one(const SimK& k, const StateIn& in, const StateOut& out,
-                                               const uint32_t* __restrict__ order, const uint32_t* __restrict__ cellStart, int s) {
-    const uint32_t src = order[s];
-    const float4 P = in.pos[src], V = in.vel[src];
-    const float2 RP = in.rp[src];
-    const float foamIn = in.foam[src];
-    const uint32_t flags = fbits(P.w), id = fbits(V.w);
-    if (flags & F_HALO) { out.pos[s] = P; return; }          // neighbour rank's particle: candidate only
-    Own o;
-    own_reset(o);
-    o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = RP.x; o.prs = RP.y;
-    if (flags & F_GHOST1) {                                  // SPHFluid.comp:72-83
-        if (!(flags & F_INACTIVE)) { o.vx = o.vy = o.vz = 0.0f; o.rho = k.rho0; o.prs = 0.0f; }
-        out.pos[s] = P;
-        out.vel[s] = make_float4(o.vx, o.vy, o.vz, V.w);
-        out.rp[s] = make_float2(o.rho, o.prs);
-        out.foam[s] = foamIn;
-        if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
-        else out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        return;
-    }
-    const int cx = cell_axis(P.x, k.gminx, k.cellSize, k.gx);
-    const int cy = cell_axis(P.y, k.gminy, k.cellSize, k.gy);
-    const int cz = cell_z_local(k, P.z);
-
-    for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
-        const float4 J = in.pos[order[q]];
-        pair_density(k, o, J.x, J.y, J.z);
-    });
-    finish_density(k, o);
-    for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
-        if ((int)q == s) return;
-        const uint32_t j = order[q];
-        const float4 J = in.pos[j], JV = in.vel[j];
-        const float2 JR = in.rp[j];
-        pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x, JR.y);
-    });
-    integrate(k, o);
-    for_each_candidate(k, cx, cy, cz, cellStart, [&](uint32_t q) {
-        if ((int)q == s) return;
-        const uint32_t j = order[q];
-        const float4 J = in.pos[j], JV = in.vel[j];
-        const float2 JR = in.rp[j];
-        pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x);
-    });
-    const float foamOut = finish_particle(k, o, foamIn);
-    store_particle(k, out, s, flags, id, o, foamOut);
-}
-
-__global__ __launch_bounds__(kBlock) void k_sph_gather(SimK k, StateIn in, StateOut out, const uint32_t* __restrict__ order,
-                                                       const uint32_t* __restrict__ cellStart, int n) {
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= n || (uint32_t)s >= cellStart[k.numCells]) return;
-    sph_gather_one(k, in, out, order, cellStart, s);
 }
 
 // ---- public AoS update (original order; the array is never permuted) ---------------------
@@ -641,24 +552,28 @@ __global__ __launch_bounds__(kBlock) void k_sph_ll(SimK k, StateIn in, StateOut 
     const int cz = cell_z_local(k, P.z);
     for_each_listed(k, cx, cy, cz, cellHead, particleNext, [&](int j) {
         const float4 J = in.pos[j];
-        pair_density(k, o, J.x, J.y, J.z);
+        pair_density(k, o, J.x, J.y, J.z, (int32_t)-1);
     });
     finish_density(k, o);
     for_each_listed(k, cx, cy, cz, cellHead, particleNext, [&](int j) {
-        if (j == i) return;
         const float4 J = in.pos[j], JV = in.vel[j];
         const float2 JR = in.rp[j];
-        pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x, JR.y);
+        pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.y, JR.x > 0.0f ? 1.0f / JR.x : 0.0f, (int32_t)(j != i ? -1 : 0));
     });
     integrate(k, o);
     for_each_listed(k, cx, cy, cz, cellHead, particleNext, [&](int j) {
-        if (j == i) return;
         const float4 J = in.pos[j], JV = in.vel[j];
         const float2 JR = in.rp[j];
-        pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x);
+        pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JR.x > 0.0f ? 1.0f / JR.x : 0.0f, (int32_t)(j != i ? -1 : 0));
     });
     const float foamOut = finish_particle(k, o, foamIn);
-    store_particle(k, out, i, flags, id, o, foamOut);
+    if (!(flags & F_GHOSTNZ)) obb_apply(k, o.px, o.py, o.pz, o.vx, o.vy, o.vz);   // OBBConstraints.comp:46
+    out.pos[i] = make_float4(o.px, o.py, o.pz, bitsf(flags));
+    out.vel[i] = make_float4(o.vx, o.vy, o.vz, bitsf(id));
+    out.rp[i] = make_float2(o.rho, o.prs);
+    out.foam[i] = foamOut;
+    if (out.aos) aos_write_fluid(out.aos, id - out.idBase, o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+    else out.acc[i] = make_float4(o.ax, o.ay, o.az, 0.0f);
 }
 
 // ======================= z-slab (multi-GPU) support ==========================================

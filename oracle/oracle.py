@@ -115,6 +115,10 @@ def lib() -> C.CDLL:
         L.sph_oracle_shape_supported.argtypes = [C.c_int]
         L.sph_oracle_shape_supported.restype = C.c_int
         L.sph_oracle_max_threads.restype = C.c_int
+        L.sph_oracle_set_contract.argtypes = [C.c_int]
+        L.sph_oracle_get_contract.restype = C.c_int
+        L.sph_oracle_rsqrt.argtypes = [C.c_float]
+        L.sph_oracle_rsqrt.restype = C.c_float
         L.sph_oracle_set_threads.argtypes = [C.c_int]
         assert L.sph_oracle_sizeof_particle() == 80
         assert L.sph_oracle_sizeof_params() == C.sizeof(OParams)
@@ -298,6 +302,20 @@ def shape_table(params):
     return tab[:n].copy(), b0
 
 
+def set_contract(c: int):
+    """1 (default): the engine's arithmetic contract; 0: the literal restatement (IEEE sqrt / division
+    exactly where SPHFluid.comp has them).  See the comment above o_sph_one in sph_oracle.c."""
+    lib().sph_oracle_set_contract(int(c))
+
+
+def get_contract() -> int:
+    return int(lib().sph_oracle_get_contract())
+
+
+def rsqrt(x: float) -> float:
+    return float(lib().sph_oracle_rsqrt(float(x)))
+
+
 def set_threads(n: int):
     lib().sph_oracle_set_threads(n)
 
@@ -313,7 +331,8 @@ def max_threads() -> int:
 # canonical order (ascending cell index of j, then ascending j).  fp32 throughout;
 # fmaf is emulated through float64 (exact product, one extra rounding that can differ
 # from a true fma in ~2^-29 of the cases, hence the 1-ulp-scale tolerance in the tests).
-# Follows shaders/SPHFluid.comp:66-221 and OBBConstraints.comp:297-330 directly.
+# Follows shaders/SPHFluid.comp:66-221 and OBBConstraints.comp:297-330 in the engine's arithmetic contract
+# (contract 1 of sph_oracle.c: same sums, accept tests and order; rsqrt / factored constants as documented there).
 # --------------------------------------------------------------------------------------
 
 _F = np.float32
@@ -325,6 +344,18 @@ def _fma(a, b, c):
 
 def _dot3(ax, ay, az, bx, by, bz):
     return _fma(az, bz, _fma(ay, by, (ax * bx).astype(np.float32)))
+
+
+def _rsqrt(x):
+    """sph_oracle_rsqrt on an fp32 array (integer seed + three Newton steps)."""
+    x = np.asarray(x, _F)
+    y = (np.uint32(0x5F3759DF) - (x.view(np.uint32) >> np.uint32(1))).view(_F)
+    xh = (_F(0.5) * x).astype(_F)
+    for _ in range(3):
+        t = (y * y).astype(_F)
+        e = _fma(-xh, t, _F(0.5))
+        y = _fma(y, e, y)
+    return y
 
 
 def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndarray:
@@ -373,20 +404,25 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
         NB[i, : len(x)] = x
     ar = np.arange(n)
 
+    mp6 = _F(mass * poly6C)
+    nhm = _F(_F(-mass) * _F(0.5))
+    max_speed2 = _F(max_speed * max_speed)
+    inv_rho0 = _F(_F(1.0) / rho0)
+    inv_foam = _F(_F(1.0) / max(_F(p.foamVelRef), _F(1e-3)))
+    tiny = _F(1e-30)
+
     out = P.copy()
-    # ---- sweep 1
-    dens = np.zeros(n, _F)
+    # ---- sweep 1: density = (mass*poly6C) * sum max(h2 - r2, 0)^3
+    dsum = np.zeros(n, _F)
     for k in range(K):
         j = NB[:, k]
         ok = j >= 0
         jj = np.where(ok, j, 0)
         d = (pos - pos[jj]).astype(_F)
         r2 = _dot3(d[:, 0], d[:, 1], d[:, 2], d[:, 0], d[:, 1], d[:, 2])
-        acc = ok & (r2 < h2)
-        t = (h2 - r2).astype(_F)
-        w = (poly6C * ((t * t).astype(_F) * t).astype(_F)).astype(_F)
-        dens = np.where(acc, _fma(mass, w, dens), dens)
-    dens = np.maximum(dens, _F(rho0 * _F(0.5)))
+        t = np.where(ok, np.maximum((h2 - r2).astype(_F), _F(0)), _F(0)).astype(_F)
+        dsum = _fma((t * t).astype(_F), t, dsum)
+    dens = np.maximum((mp6 * dsum).astype(_F), _F(rho0 * _F(0.5)))
     prs = np.maximum((kgas * (dens - rho0).astype(_F)).astype(_F), _F(0))
 
     # ---- sweep 2
@@ -394,32 +430,34 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
     fV = np.zeros((n, 3), _F)
     gC = np.zeros((n, 3), _F)
     lapC = np.zeros(n, _F)
-    with np.errstate(divide="ignore", invalid="ignore"):
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         for k in range(K):
             j = NB[:, k]
             ok = (j >= 0) & (j != ar)
             jj = np.where(j >= 0, j, 0)
             d = (pos - pos[jj]).astype(_F)
-            r = np.sqrt(_dot3(d[:, 0], d[:, 1], d[:, 2], d[:, 0], d[:, 1], d[:, 2])).astype(_F)
+            r2 = _dot3(d[:, 0], d[:, 1], d[:, 2], d[:, 0], d[:, 1], d[:, 2])
             rj = rho_in[jj]
-            acc = ok & (r < h) & (rj > 0)
+            acc = ok & (r2 < h2) & (rj > 0)
+            rinv = _rsqrt(np.maximum(r2, tiny))
+            r = (r2 * rinv).astype(_F)
             hr = (h - r).astype(_F)
-            s = (spikyC * (hr * hr).astype(_F)).astype(_F)
-            invr = (_F(1.0) / r).astype(_F)
-            gW = np.where((r > 0)[:, None], (s[:, None] * (d * invr[:, None]).astype(_F)).astype(_F), _F(0)).astype(_F)
+            sr = ((spikyC * (hr * hr).astype(_F)).astype(_F) * rinv).astype(_F)
+            gW = (sr[:, None] * d).astype(_F)
             inv_rho = (_F(1.0) / rj).astype(_F)
-            pterm = ((((-mass) * (prs + prs_in[jj]).astype(_F)).astype(_F) * _F(0.5)).astype(_F) * inv_rho).astype(_F)
             mor = (mass * inv_rho).astype(_F)
-            lapW = (viscC * hr).astype(_F)
+            pterm = (((prs + prs_in[jj]).astype(_F) * nhm).astype(_F) * inv_rho).astype(_F)
+            ml = (mor * (viscC * hr).astype(_F)).astype(_F)
             for a in range(3):
                 fP[:, a] = np.where(acc, _fma(gW[:, a], pterm, fP[:, a]), fP[:, a])
-                dv = ((vel[jj, a] - vel[:, a]).astype(_F) * mor).astype(_F)
-                fV[:, a] = np.where(acc, _fma(dv, lapW, fV[:, a]), fV[:, a])
+                fV[:, a] = np.where(acc, _fma((vel[jj, a] - vel[:, a]).astype(_F), ml, fV[:, a]), fV[:, a])
                 gC[:, a] = np.where(acc, _fma(mor, gW[:, a], gC[:, a]), gC[:, a])
-            lapC = np.where(acc, _fma(mor, lapW, lapC), lapC)
-        gl = np.sqrt(_dot3(gC[:, 0], gC[:, 1], gC[:, 2], gC[:, 0], gC[:, 1], gC[:, 2])).astype(_F)
-        sc = ((-sigma) * lapC).astype(_F)
-        fS = np.where((gl > _F(1e-6))[:, None], (sc[:, None] * (gC / gl[:, None]).astype(_F)).astype(_F), _F(0)).astype(_F)
+            lapC = np.where(acc, (lapC + ml).astype(_F), lapC)
+        gl2 = _dot3(gC[:, 0], gC[:, 1], gC[:, 2], gC[:, 0], gC[:, 1], gC[:, 2])
+        sc = np.where(gl2 > _F(1e-12), (((-sigma) * lapC).astype(_F) * _rsqrt(np.maximum(gl2, tiny))).astype(_F), _F(0)).astype(_F)
+        fS = (sc[:, None] * gC).astype(_F)
+    rr = _rsqrt(np.maximum(dens, tiny))
+    inv_rho_i = (rr * rr).astype(_F)
     accv = np.zeros((n, 3), _F)
     nvel = np.zeros((n, 3), _F)
     npos = np.zeros((n, 3), _F)
@@ -428,7 +466,7 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
         t = _fma(visc, fV[:, a], fP[:, a])
         t = (t + fG).astype(_F)
         t = (t + fS[:, a]).astype(_F)
-        accv[:, a] = (t / dens).astype(_F)
+        accv[:, a] = (t * inv_rho_i).astype(_F)
         v = _fma(accv[:, a], dt, vel[:, a])
         v = (v * _F(0.995)).astype(_F)
         nvel[:, a] = v
@@ -437,7 +475,7 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
     # ---- sweep 3 (own state updated, neighbours at entry, entry cell)
     xs = np.zeros((n, 3), _F)
     norm = np.zeros(n, _F)
-    with np.errstate(divide="ignore", invalid="ignore"):
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         for k in range(K):
             j = NB[:, k]
             ok = (j >= 0) & (j != ar)
@@ -447,22 +485,22 @@ def brute_force_sph_pass(P: np.ndarray, p: OParams, dt: float = -1.0) -> np.ndar
             rj = rho_in[jj]
             acc = ok & (r2 < h2) & (rj > 0)
             t = (h2 - r2).astype(_F)
-            w = (poly6C * ((t * t).astype(_F) * t).astype(_F)).astype(_F)
-            mor = (mass * (_F(1.0) / rj).astype(_F)).astype(_F)
+            w3 = ((t * t).astype(_F) * t).astype(_F)
+            wm = (w3 * (mass * (_F(1.0) / rj).astype(_F)).astype(_F)).astype(_F)
             for a in range(3):
-                dv = ((vel[jj, a] - nvel[:, a]).astype(_F) * w).astype(_F)
-                xs[:, a] = np.where(acc, _fma(dv, mor, xs[:, a]), xs[:, a])
-            norm = np.where(acc, (norm + w).astype(_F), norm)
-        xs = np.where((norm > 0)[:, None], (xs / norm[:, None]).astype(_F), xs).astype(_F)
+                xs[:, a] = np.where(acc, _fma((vel[jj, a] - nvel[:, a]).astype(_F), wm, xs[:, a]), xs[:, a])
+            norm = np.where(acc, (norm + w3).astype(_F), norm)
+        nr = _rsqrt(np.maximum(norm, tiny))
+        xs = np.where((norm > 0)[:, None], (xs * (nr * nr).astype(_F)[:, None]).astype(_F), xs).astype(_F)
     for a in range(3):
         nvel[:, a] = _fma(_F(0.12), xs[:, a], nvel[:, a])
-    sp = np.sqrt(_dot3(nvel[:, 0], nvel[:, 1], nvel[:, 2], nvel[:, 0], nvel[:, 1], nvel[:, 2])).astype(_F)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        f = (max_speed / sp).astype(_F)
-    nvel = np.where((sp > max_speed)[:, None], (nvel * f[:, None]).astype(_F), nvel).astype(_F)
-    speed = np.sqrt(_dot3(nvel[:, 0], nvel[:, 1], nvel[:, 2], nvel[:, 0], nvel[:, 1], nvel[:, 2])).astype(_F)
-    aer = (np.clip(((rho0 - dens).astype(_F) / rho0).astype(_F), 0, 1).astype(_F)
-           * np.clip((speed / max(_F(p.foamVelRef), _F(1e-3))).astype(_F), 0, 1).astype(_F)).astype(_F)
+    sp2 = _dot3(nvel[:, 0], nvel[:, 1], nvel[:, 2], nvel[:, 0], nvel[:, 1], nvel[:, 2])
+    f = (max_speed * _rsqrt(np.maximum(sp2, tiny))).astype(_F)
+    nvel = np.where((sp2 > max_speed2)[:, None], (nvel * f[:, None]).astype(_F), nvel).astype(_F)
+    s2 = _dot3(nvel[:, 0], nvel[:, 1], nvel[:, 2], nvel[:, 0], nvel[:, 1], nvel[:, 2])
+    speed = (s2 * _rsqrt(np.maximum(s2, tiny))).astype(_F)
+    aer = (np.clip(((rho0 - dens).astype(_F) * inv_rho0).astype(_F), 0, 1).astype(_F)
+           * np.clip((speed * inv_foam).astype(_F), 0, 1).astype(_F)).astype(_F)
     foam = np.maximum((aer * _F(p.foamGen)).astype(_F), (P["padA"] * _F(0.995)).astype(_F))
 
     fluid = P["isGhost"] != 1

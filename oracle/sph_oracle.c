@@ -276,9 +276,19 @@ static void o_consts(const OParams* p, float dt, OConsts* k) {
     k->foamGen = p->foamGen; k->foamVelRef = p->foamVelRef;
 }
 
-/* SPHFluid.comp main(), :66-221, for particle i, snapshot semantics. */
-static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g,
-                      const int32_t* cellStart, const int32_t* sorted, const OConsts* k) {
+/* Stencil traversal of the literal restatement: canonical (dz outer, dy, dx inner; ascending index
+ * inside a cell) or, with shaderOrder, the shader's own nesting dx -> dy -> dz (SPHFluid.comp:91-93)
+ * with each cell's list in DESCENDING index order -- the list BuildGrid.comp's push-front produces
+ * when invocations happen to run in index order, i.e. ONE legal order of the reference itself. */
+#define O_STENCIL(it, shaderOrder) \
+    const int dx = (shaderOrder) ? ((it) / 9 - 1) : ((it) % 3 - 1); \
+    const int dy = ((it) / 3) % 3 - 1; \
+    const int dz = (shaderOrder) ? ((it) % 3 - 1) : ((it) / 9 - 1)
+/* SPHFluid.comp main(), :66-221, for particle i, snapshot semantics: the LITERAL restatement (contract 0:
+ * IEEE sqrt and division exactly where the shader has them).  Kept as the yardstick the engine's
+ * arithmetic contract (o_sph_one below) is measured against (tests/test_oracle_contract.py). */
+static void o_sph_one_literal(int i, const OParticle* in, OParticle* out, const OGrid* g,
+                      const int32_t* cellStart, const int32_t* sorted, const OConsts* k, int shaderOrder) {
     OParticle pi = in[i];
     if (pi.isGhost == 1) {                                   /* :72-83 */
         if (pi.isActive == 0) { out[i] = pi; return; }
@@ -296,11 +306,13 @@ static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g
 
     /* ---- sweep 1: density, :90-106 (self included) ---- */
     float density = 0.0f;
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+    for (int it = 0; it < 27; ++it) {
+        O_STENCIL(it, shaderOrder);
         int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
         if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
         int cell = (nz * gy + ny) * gx + nx;
-        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+        for (int qq = cellStart[cell]; qq < cellStart[cell + 1]; ++qq) {
+            const int q = shaderOrder ? (cellStart[cell] + cellStart[cell + 1] - 1 - qq) : qq;
             const OParticle* pj = &in[sorted[q]];
             float ddx = pi.pos[0] - pj->pos[0], ddy = pi.pos[1] - pj->pos[1], ddz = pi.pos[2] - pj->pos[2];
             float r2 = o_dot3(ddx, ddy, ddz, ddx, ddy, ddz);
@@ -318,11 +330,13 @@ static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g
     /* ---- sweep 2: forces, :113-155 (self skipped) ---- */
     float fP[3] = { 0, 0, 0 }, fV[3] = { 0, 0, 0 }, gradC[3] = { 0, 0, 0 };
     float lapC = 0.0f;
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+    for (int it = 0; it < 27; ++it) {
+        O_STENCIL(it, shaderOrder);
         int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
         if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
         int cell = (nz * gy + ny) * gx + nx;
-        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+        for (int qq = cellStart[cell]; qq < cellStart[cell + 1]; ++qq) {
+            const int q = shaderOrder ? (cellStart[cell] + cellStart[cell + 1] - 1 - qq) : qq;
             int j = sorted[q];
             if (j == i) continue;
             const OParticle* pj = &in[j];
@@ -373,11 +387,13 @@ static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g
      *      cell coordinate NOT recomputed) ---- */
     float xs[3] = { 0, 0, 0 };
     float norm = 0.0f;
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+    for (int it = 0; it < 27; ++it) {
+        O_STENCIL(it, shaderOrder);
         int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
         if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
         int cell = (nz * gy + ny) * gx + nx;
-        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+        for (int qq = cellStart[cell]; qq < cellStart[cell + 1]; ++qq) {
+            const int q = shaderOrder ? (cellStart[cell] + cellStart[cell + 1] - 1 - qq) : qq;
             int j = sorted[q];
             if (j == i) continue;
             const OParticle* pj = &in[j];
@@ -410,6 +426,184 @@ static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g
     }
     out[i] = pi;                                             /* :220 */
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * The engine's arithmetic contract (contract 1, the default; semantic 11 in the header).
+ * Same sums, same candidate order, same accept tests as o_sph_one_literal; what changes is HOW a
+ * few quantities are formed, so that the per-pair arithmetic is add / mul / fma only (it then packs
+ * two pairs per v_pk_*_f32 instruction on gfx950) and costs no IEEE sqrt / division per pair:
+ *   - 1/sqrt(x) is o_rsqrt(): integer seed + three Newton steps, |rel. error| <= 2 ulp -- inside
+ *     GLSL's own tolerance for inversesqrt (2 ULP, GLSL 4.50 spec section 4.7.1);
+ *     sqrt(x) = x * o_rsqrt(x), 1/x = o_rsqrt(x)^2 (own density, XSPH norm);
+ *   - constant factors are taken out of the sums: density = (mass*poly6C) * sum (h2-r2)^3; the XSPH
+ *     quotient sum(dv W m/rho) / sum(W) drops the poly6 coefficient from both sums;
+ *   - spikyGrad = (spikyC (h-r)^2 / r) * rij instead of spikyC (h-r)^2 * (rij / r);
+ *     viscosity term (vj-vi) * ((m/rho_j) lapW) instead of ((vj-vi) (m/rho_j)) * lapW;
+ *   - `r < h` is tested as r2 < h2 and `length(v) > maxSpeed` as |v|^2 > maxSpeed^2.
+ * Rejected candidates add exactly +0, so "skip" and "add zero" are the same bits (the HIP kernels
+ * are branch-free).
+ * ------------------------------------------------------------------------------------------- */
+static inline uint32_t o_fbits(float f);
+static inline float o_bitsf(uint32_t u);
+float sph_oracle_rsqrt(float x) {                            /* x > 0, normal */
+    uint32_t u; memcpy(&u, &x, 4);
+    u = 0x5f3759dfu - (u >> 1);
+    float y; memcpy(&y, &u, 4);
+    const float xh = 0.5f * x;
+    for (int it = 0; it < 3; ++it) {
+        float t = y * y;
+        float e = fmaf(-xh, t, 0.5f);
+        y = fmaf(y, e, y);
+    }
+    return y;
+}
+#define O_TINY 1e-30f
+
+static void o_sph_one(int i, const OParticle* in, OParticle* out, const OGrid* g,
+                      const int32_t* cellStart, const int32_t* sorted, const OConsts* k) {
+    OParticle pi = in[i];
+    if (pi.isGhost == 1) {                                   /* :72-83 */
+        if (pi.isActive == 0) { out[i] = pi; return; }
+        pi.vel[0] = pi.vel[1] = pi.vel[2] = pi.vel[3] = 0.0f;
+        pi.acc[0] = pi.acc[1] = pi.acc[2] = pi.acc[3] = 0.0f;
+        pi.density = k->restDensity;
+        pi.pressure = 0.0f;
+        out[i] = pi;
+        return;
+    }
+    int cc[3];
+    o_cell_coord(g, pi.pos, cc);                             /* :85-87 */
+    const int gx = g->dims[0], gy = g->dims[1], gz = g->dims[2];
+    const float h = k->h, h2 = k->h2, mass = k->mass;
+    const float mp6 = mass * k->poly6C;
+    const float nhm = (-mass) * 0.5f;
+    const float maxSpeed2 = k->maxSpeed * k->maxSpeed;
+    const float invRho0 = 1.0f / k->restDensity;
+    const float invFoamRef = 1.0f / fmaxf(k->foamVelRef, 1e-3f);
+
+    /* ---- sweep 1: density, :90-106 (self included) ---- */
+    float dsum = 0.0f;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
+        int cell = (nz * gy + ny) * gx + nx;
+        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+            const OParticle* pj = &in[sorted[q]];
+            float ddx = pi.pos[0] - pj->pos[0], ddy = pi.pos[1] - pj->pos[1], ddz = pi.pos[2] - pj->pos[2];
+            float r2 = o_dot3(ddx, ddy, ddz, ddx, ddy, ddz);
+            float t = fmaxf(h2 - r2, 0.0f);                  /* r2 >= h2 adds +0 */
+            dsum = fmaf(t * t, t, dsum);
+        }
+    }
+    pi.density = fmaxf(mp6 * dsum, k->restDensity * 0.5f);   /* :106 */
+    pi.pressure = fmaxf(k->gasConstant * (pi.density - k->restDensity), 0.0f);   /* :111 */
+
+    /* ---- sweep 2: forces, :113-155 (self skipped) ---- */
+    float fP[3] = { 0, 0, 0 }, fV[3] = { 0, 0, 0 }, gradC[3] = { 0, 0, 0 };
+    float lapC = 0.0f;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
+        int cell = (nz * gy + ny) * gx + nx;
+        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+            int j = sorted[q];
+            if (j == i) continue;
+            const OParticle* pj = &in[j];
+            float rij[3] = { pi.pos[0] - pj->pos[0], pi.pos[1] - pj->pos[1], pi.pos[2] - pj->pos[2] };
+            float r2 = o_dot3(rij[0], rij[1], rij[2], rij[0], rij[1], rij[2]);
+            if (r2 < h2 && pj->density > 0.0f) {
+                float rinv = sph_oracle_rsqrt(fmaxf(r2, O_TINY));
+                float r = r2 * rinv;
+                float hr = h - r;
+                float sr = (k->spikyC * (hr * hr)) * rinv;   /* spikyGrad :50-57 = sr * rij (0 for rij = 0) */
+                float gW[3] = { sr * rij[0], sr * rij[1], sr * rij[2] };
+                float invRho = 1.0f / pj->density;           /* semantic 9: once per neighbour */
+                float mor = mass * invRho;
+                float pterm = ((pi.pressure + pj->pressure) * nhm) * invRho;
+                float ml = mor * (k->viscC * hr);            /* viscLaplacian :58-64 times m/rho_j */
+                for (int a = 0; a < 3; ++a) {
+                    fP[a] = fmaf(gW[a], pterm, fP[a]);
+                    fV[a] = fmaf(pj->vel[a] - pi.vel[a], ml, fV[a]);
+                    gradC[a] = fmaf(mor, gW[a], gradC[a]);
+                }
+                lapC = lapC + ml;
+            }
+        }
+    }
+    float fS[3];                                             /* :157-163 */
+    float gl2 = o_dot3(gradC[0], gradC[1], gradC[2], gradC[0], gradC[1], gradC[2]);
+    {
+        float sc = (gl2 > 1e-12f) ? (((-k->surfaceTension) * lapC) * sph_oracle_rsqrt(gl2)) : 0.0f;
+        for (int a = 0; a < 3; ++a) fS[a] = sc * gradC[a];   /* branch-free form of the kernels: sc = +0 below the threshold */
+    }
+    {
+        float rr = sph_oracle_rsqrt(fmaxf(pi.density, O_TINY));
+        float invRhoI = rr * rr;
+        for (int a = 0; a < 3; ++a) {                        /* :165-171 */
+            float fG = k->g[a] * pi.density;
+            float t = fmaf(k->viscosity, fV[a], fP[a]);
+            t = t + fG;
+            t = t + fS[a];
+            float acc = t * invRhoI;
+            pi.acc[a] = acc;
+            pi.vel[a] = fmaf(acc, k->dt, pi.vel[a]);
+            pi.vel[a] = pi.vel[a] * 0.995f;
+            pi.pos[a] = fmaf(pi.vel[a], k->dt, pi.pos[a]);
+        }
+    }
+    pi.acc[3] = 0.0f;
+
+    /* ---- sweep 3: XSPH, :177-201 (own state updated, neighbours at entry, cell NOT recomputed) ---- */
+    float xs[3] = { 0, 0, 0 };
+    float norm = 0.0f;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+        int nx = cc[0] + dx, ny = cc[1] + dy, nz = cc[2] + dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= gx || ny >= gy || nz >= gz) continue;
+        int cell = (nz * gy + ny) * gx + nx;
+        for (int q = cellStart[cell]; q < cellStart[cell + 1]; ++q) {
+            int j = sorted[q];
+            if (j == i) continue;
+            const OParticle* pj = &in[j];
+            float ddx = pi.pos[0] - pj->pos[0], ddy = pi.pos[1] - pj->pos[1], ddz = pi.pos[2] - pj->pos[2];
+            float r2 = o_dot3(ddx, ddy, ddz, ddx, ddy, ddz);
+            if (r2 < h2 && pj->density > 0.0f) {
+                float t = h2 - r2;
+                float w3 = (t * t) * t;
+                float wm = w3 * (mass * (1.0f / pj->density));
+                for (int a = 0; a < 3; ++a) xs[a] = fmaf(pj->vel[a] - pi.vel[a], wm, xs[a]);
+                norm = norm + w3;
+            }
+        }
+    }
+    if (norm > 0.0f) {
+        float nr = sph_oracle_rsqrt(fmaxf(norm, O_TINY));
+        float ninv = nr * nr;
+        xs[0] = xs[0] * ninv; xs[1] = xs[1] * ninv; xs[2] = xs[2] * ninv;
+    }
+    for (int a = 0; a < 3; ++a) pi.vel[a] = fmaf(0.12f, xs[a], pi.vel[a]);
+
+    {                                                        /* velocity cap :203-207 */
+        float sp2 = o_dot3(pi.vel[0], pi.vel[1], pi.vel[2], pi.vel[0], pi.vel[1], pi.vel[2]);
+        if (sp2 > maxSpeed2) {
+            float f = k->maxSpeed * sph_oracle_rsqrt(sp2);
+            pi.vel[0] = pi.vel[0] * f; pi.vel[1] = pi.vel[1] * f; pi.vel[2] = pi.vel[2] * f;
+        }
+    }
+    {                                                        /* foam :209-217 */
+        float sp2 = o_dot3(pi.vel[0], pi.vel[1], pi.vel[2], pi.vel[0], pi.vel[1], pi.vel[2]);
+        float speed = sp2 * sph_oracle_rsqrt(fmaxf(sp2, O_TINY));
+        float aer = o_clampf((k->restDensity - pi.density) * invRho0, 0.0f, 1.0f)
+                  * o_clampf(speed * invFoamRef, 0.0f, 1.0f);
+        pi.padA = fmaxf(aer * k->foamGen, pi.padA * 0.995f);
+    }
+    out[i] = pi;                                             /* :220 */
+}
+
+/* 1 = the engine's contract (o_sph_one); 0 = literal restatement, canonical order; 2 = literal
+ * restatement in the shader's own traversal order (see O_STENCIL) */
+static int g_contract = 1;
+void sph_oracle_set_contract(int c) { g_contract = (c == 0 || c == 2) ? c : 1; }
+int sph_oracle_get_contract(void) { return g_contract; }
 
 /* OBBConstraints.comp, box branch :297-309 and response :311-330.  Other shape
  * types are handled by sph_oracle_obb_shape() below. */
@@ -827,8 +1021,13 @@ void sph_oracle_sph_pass(const OParticle* in, OParticle* out, int n, const OPara
     int32_t* sorted = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     int32_t* pcell = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     sph_oracle_build_grid(in, n, &g, cellStart, sorted, pcell, NULL, NULL);
+    if (g_contract == 1) {
 #pragma omp parallel for schedule(dynamic, 256)
-    for (int i = 0; i < n; ++i) o_sph_one(i, in, out, &g, cellStart, sorted, &k);
+        for (int i = 0; i < n; ++i) o_sph_one(i, in, out, &g, cellStart, sorted, &k);
+    } else {
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int i = 0; i < n; ++i) o_sph_one_literal(i, in, out, &g, cellStart, sorted, &k, g_contract == 2);
+    }
     free(cellStart); free(sorted); free(pcell);
 }
 

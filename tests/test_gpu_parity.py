@@ -13,17 +13,14 @@ from conftest import assert_records_equal, small_scene, to_oracle_params
 
 pytestmark = pytest.mark.gpu
 
-NEIGHBOR_VARIANTS = [("tile", 0), ("gather", 1), ("gather2", 2)]
+NEIGHBOR_VARIANTS = [("slow", 1), ("pair", 2)]      # k_sph_slow (plain statement) and k_sph_pair (default)
 
 
-def make_engine(pkg, rec, sp, neighbor=0, debug=0, tile=None, aos_lazy=False):
+def make_engine(pkg, rec, sp, neighbor=2, debug=0, aos_lazy=False):
     f = pkg.SPHFluidGPU.from_particles(rec, sp)
     f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)
     if debug:
         f.set_option(pkg.SPH_OPT_DEBUG, debug)
-    if tile:
-        for opt, v in zip((103, 102, 101), tile[::-1]):      # z, y, x: every intermediate shape fits the LDS tables
-            f.set_option(opt, v)
     if aos_lazy:
         f.set_option(pkg.SPH_OPT_AOS_MODE, 1)
     return f
@@ -85,22 +82,26 @@ def test_config1_100_substeps(pkg, oracle, name, neighbor):
 
 
 @pytest.mark.parametrize("debug", [1, 2, 3, 4])
-def test_tile_fallback_paths_bit_exact(pkg, oracle, debug):
-    """bit 0: neighbour-list overflow -> LDS re-scan; bit 1: sweep-3 displacement fallback;
-    bit 2: tile overflow -> global gather.  Every path must give identical bits."""
+def test_pair_fallback_paths_bit_exact(pkg, oracle, debug):
+    """k_sph_pair's exact fallbacks forced for every target -- bit 0: neighbour-list overflow, bit 1: a target
+    outside the list's slack after integrate, bit 2: window overflow (whole wave).  Identical bits."""
     rec, sp = small_scene(pkg, n=4096, grid=16, seed=33)
-    f = make_engine(pkg, rec, sp, 0, debug=debug)
+    f = make_engine(pkg, rec, sp, 2, debug=debug | 8)
     f.DispatchN(5)
     assert_records_equal(f.download(), oracle.substep(rec, to_oracle_params(oracle, sp), steps=5), f"debug={debug}")
+    c = f.debug_counters()
+    assert (c["slow_waves"] > 0) if (debug & 4) else (c["slow_targets"] >= 5 * 4096)
     f.close()
 
 
-@pytest.mark.parametrize("tile", [(8, 4, 4), (4, 4, 4), (16, 2, 2), (3, 5, 2), (8, 6, 6), (1, 1, 1)])
-def test_tile_shape_does_not_change_results(pkg, oracle, tile):
-    rec, sp = small_scene(pkg, n=4096, grid=16, seed=34)
-    f = make_engine(pkg, rec, sp, 0, tile=tile)
-    f.DispatchN(3)
-    assert_records_equal(f.download(), oracle.substep(rec, to_oracle_params(oracle, sp), steps=3), f"tile={tile}")
+def test_pair_fast_path_is_the_one_running(pkg, oracle):
+    """On the lattice scene nothing may fall back: the LDS windows and the lists hold every target."""
+    rec, sp = small_scene(pkg, n=4096, grid=16, seed=33)
+    f = make_engine(pkg, rec, sp, 2, debug=8)
+    f.DispatchN(5)
+    c = f.debug_counters()
+    assert_records_equal(f.download(), oracle.substep(rec, to_oracle_params(oracle, sp), steps=5), "fast path")
+    assert c["slow_waves"] == 0 and c["slow_targets"] == 0 and c["list_entries"] > 0, c
     f.close()
 
 
@@ -144,7 +145,7 @@ def test_container_shapes(pkg, oracle, shape):
     f.close()
 
 
-@pytest.mark.parametrize("neighbor,aos", [(1, 0), (0, 1), (2, 0)])
+@pytest.mark.parametrize("neighbor,aos", [(1, 0), (2, 1), (2, 0)])
 def test_ext_shape_other_paths(pkg, oracle, neighbor, aos):
     """A deferred-OBB shape through the gather kernel and with the lazy 80-byte array; the shape
     changes between dispatches (table re-upload), as the ImGui shape picker does (Scene0p.cpp:2380-2470)."""
@@ -272,7 +273,7 @@ def test_all_particles_in_one_cell(pkg, oracle):
     rec = np.zeros(3000, pkg.PARTICLE_DTYPE)
     rec["pos"][:, :3] = rng.uniform(0.01, 0.27, (3000, 3)).astype(np.float32)
     op = to_oracle_params(oracle, sp)
-    for neighbor in (0, 1, 2):
+    for neighbor in (1, 2):
         f = make_engine(pkg, rec, sp, neighbor)
         cnt, _ = f.download_grid()
         assert cnt.max() == 3000
@@ -283,19 +284,18 @@ def test_all_particles_in_one_cell(pkg, oracle):
 
 def test_full_size_properties_config3(pkg):
     """4M particles / 128^3 (BASELINE.json configs[2]) is too big for the oracle in a test, so
-    check size-independent properties: tiled == gather bit for bit, velocity cap, containment."""
+    check size-independent properties: k_sph_pair == k_sph_slow bit for bit, velocity cap, containment."""
     syn = pkg.synthetic
     cfg = syn.CONFIGS[3]
     rec, _ = syn.make_particles(cfg)
     sp = pkg.default_params(**syn.params_fields(cfg))
     outs = []
-    for neighbor in (0, 1, 2):
+    for neighbor in (1, 2):
         f = make_engine(pkg, rec, sp, neighbor)
         f.DispatchN(3)
         outs.append(f.download())
         f.close()
-    assert_records_equal(outs[0], outs[1], "tile vs gather at 4M")
-    assert_records_equal(outs[0], outs[2], "tile vs gather2 at 4M")
+    assert_records_equal(outs[0], outs[1], "k_sph_slow vs k_sph_pair at 4M")
     out = outs[0]
     half = syn.box_half_for_grid(cfg.grid)
     assert np.all(np.abs(out["pos"][:, :3]) <= half[None, :] + 1e-4)
@@ -303,39 +303,21 @@ def test_full_size_properties_config3(pkg):
     assert out["density"].min() >= 500.0 and np.isfinite(out["pos"]).all()
 
 
-@pytest.mark.parametrize("scale", [0.75, 0.6, 0.45])
-def test_dense_fluid_stays_on_the_tiled_path(pkg, oracle, scale):
-    """Compressed fluid: 2.4x / 4.6x / 11x the lattice density, i.e. 27-cell candidate lists far
-    beyond one 96-bit mask.  The tiled pass thins its slices, widens the list stride and walks
-    the lists in 96-candidate chunks; results stay bit-identical and (almost) nothing is left
-    to the slow queue."""
-    rec, sp = small_scene(pkg, n=4096, grid=16, seed=40)
-    op = to_oracle_params(oracle, sp)
-    P = oracle.substep(rec, op, steps=2)
-    P["pos"][:, :3] *= np.float32(scale)
-    f = make_engine(pkg, P, sp, 0, debug=8)
-    f.DispatchN(3)
-    c = f.debug_counters()
-    assert_records_equal(f.download(), oracle.substep(P, op, steps=3), f"scale {scale}")
-    print(f"scale {scale}: slices/tile {c['slices'] / c['tiles']:.2f} groups/waveround {c['scangroups'] / max(c['waverounds'], 1):.1f} "
-          f"slow {c['slow_lanes']} overflow slices {c['overflow_slices']} targets {c['targets']}")
-    assert c["scangroups"] / max(c["waverounds"], 1) > 12          # the chunked path really ran
-    if scale >= 0.6:
-        assert c["slow_lanes"] == 0 and c["overflow_slices"] == 0
-    f.close()
-
-
 @pytest.mark.parametrize("scale", [0.75, 0.45, 0.3])
-def test_dense_fluid_gather2(pkg, oracle, scale):
-    """The sorted-gather pass on compressed fluid: neighbour lists beyond the 64 LDS entries per
-    thread (scale 0.45: ~11x, 0.3: ~37x the lattice density) fall back to full candidate sweeps."""
+def test_dense_fluid_pair(pkg, oracle, scale):
+    """Compressed fluid (2.4x / 11x / 37x the lattice density): windows and lists overflow, the exact
+    fallbacks take over wave by wave / target by target; the bits do not change."""
     rec, sp = small_scene(pkg, n=4096, grid=16, seed=41)
     op = to_oracle_params(oracle, sp)
     P = oracle.substep(rec, op, steps=2)
     P["pos"][:, :3] *= np.float32(scale)
-    f = make_engine(pkg, P, sp, 2)
+    f = make_engine(pkg, P, sp, 2, debug=8)
     f.DispatchN(3)
-    assert_records_equal(f.download(), oracle.substep(P, op, steps=3), f"gather2 scale {scale}")
+    assert_records_equal(f.download(), oracle.substep(P, op, steps=3), f"pair scale {scale}")
+    c = f.debug_counters()
+    print(f"scale {scale}: {c}")
+    if scale <= 0.45:
+        assert c["slow_waves"] + c["slow_targets"] > 0
     f.close()
 
 

@@ -29,7 +29,7 @@ def _cell_z(pkg, sp, P):
     return np.clip(np.floor(q), 0, g.dims[2] - 1).astype(np.int64), tuple(g.dims)
 
 
-def _group(pkg, halo, P, sp, world, neighbor=0):
+def _group(pkg, halo, P, sp, world, neighbor=2):
     import torch
     cz, dims = _cell_z(pkg, sp, P)
     ids = np.arange(len(P), dtype=np.uint32)
@@ -43,7 +43,7 @@ def _group(pkg, halo, P, sp, world, neighbor=0):
                                          lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), 8192, cz)
 
 
-@pytest.mark.parametrize("neighbor", [0, 1, 2])
+@pytest.mark.parametrize("neighbor", [1, 2])
 @pytest.mark.parametrize("world", [1, 2, 3, 5])
 def test_slabs_match_single_engine_and_oracle(pkg, oracle, world, neighbor):
     halo = importlib.import_module(PKG_NAME + ".halo")

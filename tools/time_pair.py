@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""SPH-pass time of both passes on a config: time_pair.py [config=3] [warm=5] [steps=20] [check 0|1]"""
+import importlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("componentframeworks-smoothed-particle-hydrodynamics_amd")
+syn = pkg.synthetic
+ci = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+check = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+cfg = syn.CONFIGS[ci]
+rec, _ = syn.make_particles(cfg)
+sp = pkg.default_params(**syn.params_fields(cfg))
+outs = {}
+for nb in ((2, 1) if check else (2,)):
+    f = pkg.SPHFluidGPU.from_particles(rec, sp)
+    f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, nb)
+    f.DispatchN(warm)
+    f.set_option(pkg.SPH_OPT_TIMING, 1)
+    f.kernel_times(reset=True)
+    f.DispatchN(steps)
+    kt = f.kernel_times(reset=True)
+    print(json.dumps({"config": cfg.name, "neighbor": nb, "us": {k: round(ms / max(c, 1) * 1e3, 1) for k, (ms, c) in kt.items() if c}}), flush=True)
+    if check:
+        outs[nb] = f.download()
+    f.close()
+if check:
+    a, b = outs[2], outs[1]
+    print("identical" if a.tobytes() == b.tobytes() else f"DIFFER in {int((a.view(np.uint8).reshape(len(a), -1) != b.view(np.uint8).reshape(len(b), -1)).any(axis=1).sum())} records")
