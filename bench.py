@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
-    ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 = k_sph_pair (engine default), 1 = k_sph_slow (plain per-target sweeps)")
+    ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 = k_sph_list (engine default), 1 = k_sph_slow (plain per-target sweeps)")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="substeps of the CPU sample (0 = auto, about 10-30 s)")
@@ -186,7 +186,7 @@ def main():
         if args.gpus == 1 and args.grid_build == "sort":
             # untimed, for the record: the two other (bit-identical) SPH passes at the state the run has reached
             alt = {}
-            for name, kind in (("k_sph_pair", 2), ("k_sph_slow", 1)):
+            for name, kind in (("k_sph_list", 2), ("k_sph_slow", 1)):
                 sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, kind)
                 sim.set_option(pkg.SPH_OPT_TIMING, 2)
                 sim.kernel_times(reset=True)
@@ -228,7 +228,7 @@ def main():
     if traffic is not None and os.path.exists(vpath) and sph_avg_s > 0:
         try:
             vj = json.load(open(vpath))
-            kname = (None, "k_sph_slow", "k_sph_pair")[args.neighbor]
+            kname = (None, "k_sph_slow", "k_sph_list")[args.neighbor]
             insts = next(v["SQ_INSTS_VALU"]["mean"] for k, v in vj.items() if kname + "<" in k or k.endswith(kname))
             peak = 256 * 4 * 2.4e9 / 4.0
             valu = {"wave_insts_per_launch": insts, "issue_peak_per_s": peak, "frac_of_issue_peak": insts / sph_avg_s / peak,
@@ -245,12 +245,12 @@ def main():
                         + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")"
                         + ("" if backend == "nccl" else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]"),
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
-            "neighbor_kernel": (None, "k_sph_slow", "k_sph_pair")[args.neighbor], "aos": args.aos,
+            "neighbor_kernel": (None, "k_sph_slow", "k_sph_list")[args.neighbor], "aos": args.aos,
             "pipeline": ("bin+scan+scatter+rank -> sph(27-cell, OBB + AoS update fused)" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB + AoS update fused)") + (" + halo exchange" if args.gpus > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_pair")[args.neighbor]),
+            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list")[args.neighbor]),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },

@@ -66,7 +66,7 @@ __device__ __forceinline__ int cell_z_local(const SimK& k, float pz) {
 
 // ======================= SPHFluid.comp main(), per-particle / per-pair arithmetic =======================
 // Written once as templates over T = float (one target per thread: k_sph_slow, k_sph_ll, exact fallbacks)
-// and T = v2f (two targets per lane, one v_pk_*_f32 per operation: k_sph_pair).  Packed fp32 operations
+// and T = v2f (two targets per lane, one v_pk_*_f32 per operation: k_sph_list).  Packed fp32 operations
 // round each half exactly like the scalar instruction, so both instantiations give the same bits.
 //
 // ARITHMETIC CONTRACT (shared with oracle/sph_oracle.c o_sph_one, DESIGN.md "Numerics"): the sums, the

@@ -16,7 +16,7 @@
 #include "../../include/sph_abi.h"
 #include "sph_host.h"
 #include "sph_kernels.h"
-#include "sph_pair.h"
+#include "sph_pass.h"
 
 static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
 
@@ -112,7 +112,7 @@ struct SphEngine {
     sph::ShapeTab shapeTab{};
     uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count
     int debugFlags = 0;
-    unsigned long long* d_stats = nullptr;   // k_sph_pair diagnostics (SPH_OPT_DEBUG bit 3), see sph_debug_counters
+    unsigned long long* d_stats = nullptr;   // k_sph_list diagnostics (SPH_OPT_DEBUG bit 3), see sph_debug_counters
 
     std::vector<SphParticle> hostInit;   // SPHFluidGPU::particles: initial state only
 
@@ -381,8 +381,7 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
         Timed t(e, SPH_K_SPH);
         if (e->optNeighbor == 2) {
-            const int units = (n + 127) / 128;
-            hipLaunchKernelGGL((k_sph_pair<SPH_PAIR_LN, SPH_PAIR_WCAP>), dim3(8 * ((units + 7) / 8)), dim3(64), 0, e->stream, k, S, in, out,
+            hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n) + 7) / 8)), dim3(kBlock), 0, e->stream, k, S, in, out,
                                e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
         } else {
             hipLaunchKernelGGL(k_sph_slow, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, n);
@@ -570,7 +569,7 @@ int sph_get_params(const SphEngine* e, SphParams* out) {
 int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
-    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 2) return fail(SPH_ERR_ARG, "SPH pass %d: 2 = k_sph_pair, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 2) return fail(SPH_ERR_ARG, "SPH pass %d: 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;

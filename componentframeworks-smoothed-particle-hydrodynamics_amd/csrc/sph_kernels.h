@@ -5,7 +5,7 @@
 //   k_scan_*   exclusive scan of the histogram, clears it for the next substep (ClearGrid.comp)
 //   k_scatter  counting-sort scatter into cell-contiguous slots (replaces cellHead/particleNext)
 //   k_rank     canonical order inside a cell: ascending particle id (makes fp32 sums reproducible)
-//   k_sph_*    (sph_pair.h) 27-cell density -> pressure -> forces -> integrate -> XSPH -> cap -> foam, with
+//   k_sph_*    (sph_pass.h) 27-cell density -> pressure -> forces -> integrate -> XSPH -> cap -> foam, with
 //              OBBConstraints.comp fused into the epilogue (legal: neighbours are read from the
 //              entry snapshot, the own record is private to the thread)
 //   k_writeback  update of the public 80-byte AoS in ORIGINAL particle order
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
 // (atomic arrival order in k_bin is arbitrary, exactly like BuildGrid.comp's atomicExchange;
 // this pass removes that freedom.)  order[s] = source index of the particle in sorted slot s.
 // With COPY the pass also writes the physically sorted copy of the entry state that the SPH pass
-// reads (sph_pair.h SortedIn: 48 B per particle; 1/rho is the one correctly rounded division per
+// reads (sph_pass.h SortedIn: 48 B per particle; 1/rho is the one correctly rounded division per
 // neighbour of the numerics contract, item 9).
 template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,

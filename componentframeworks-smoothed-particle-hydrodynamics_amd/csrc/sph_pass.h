@@ -1,0 +1,255 @@
+// sph_pass.h -- the SPH pass (SPHFluid.comp:66-221 + fused OBBConstraints.comp) of the engine.
+//
+//   k_sph_list  (default)  one target per lane over the physically sorted copy: wave-cooperative LDS windows for the
+//               candidate scan (density + neighbour list), sweeps 2 / 3 over the listed neighbours only.
+//   k_sph_slow  one target per thread, three full candidate sweeps straight from global memory: the plain statement
+//               of the same arithmetic (A/B variant SPH_OPT_NEIGHBOR_KERNEL = 1).
+// Same functions (sph_device.h), same candidate order, therefore the same bits.
+#pragma once
+#include <type_traits>
+
+#include "sph_kernels.h"
+
+namespace sph {
+
+struct SortedIn {
+    const float4* __restrict__ posI;   // (x, y, z, 1/rho or 0)  in (cell, id) order of THIS substep
+    const float4* __restrict__ velP;   // (vx, vy, vz, P)
+    const float4* __restrict__ own;    // (bits(cx | cy << 10 | cz << 20), foam, bits(flags), bits(id))
+};   // written by k_rank<true>
+
+__device__ __forceinline__ void store_fields(const SimK& k, const StateOut& out, int s, uint32_t flags, uint32_t id, float px, float py,
+                                             float pz, float vx, float vy, float vz, float ax, float ay, float az, float rho, float prs,
+                                             float foamOut) {
+    if (!(flags & F_GHOSTNZ)) obb_apply(k, px, py, pz, vx, vy, vz);   // OBBConstraints.comp:46
+    out.pos[s] = make_float4(px, py, pz, bitsf(flags));
+    out.vel[s] = make_float4(vx, vy, vz, bitsf(id));
+    out.rp[s] = make_float2(rho, prs);
+    out.foam[s] = foamOut;
+    if (out.aos) aos_write_fluid(out.aos, id - out.idBase, px, py, pz, vx, vy, vz, ax, ay, az, rho, prs, foamOut);
+    else out.acc[s] = make_float4(ax, ay, az, 0.0f);
+}
+
+// Halo copy / ghost branch of SPHFluid.comp:72-83 for sorted slot s.  Returns true when the slot is done.
+__device__ __forceinline__ bool special_slot(const SimK& k, const SortedIn& S, const StateIn& in, const StateOut& out,
+                                             const uint32_t* __restrict__ order, int s, const float4& P, const float4& V, const float4& O) {
+    const uint32_t flags = fbits(O.z), id = fbits(O.w);
+    if (flags & F_HALO) { out.pos[s] = make_float4(P.x, P.y, P.z, O.z); return true; }   // neighbour rank's particle: candidate only
+    if (flags & F_GHOST1) {
+        float gvx = V.x, gvy = V.y, gvz = V.z, grho = in.rp[order[s]].x, gprs = V.w;
+        if (!(flags & F_INACTIVE)) { gvx = gvy = gvz = 0.0f; grho = k.rho0; gprs = 0.0f; }
+        out.pos[s] = make_float4(P.x, P.y, P.z, O.z);
+        out.vel[s] = make_float4(gvx, gvy, gvz, O.w);
+        out.rp[s] = make_float2(grho, gprs);
+        out.foam[s] = O.y;
+        if (out.aos) { if (!(flags & F_INACTIVE)) aos_write_active_ghost(out.aos, id - out.idBase, k.rho0); }
+        else out.acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return true;
+    }
+    return false;
+}
+
+// One target, everything from global memory, candidates in canonical order.
+__device__ __forceinline__ void sph_slow_one(const SimK& k, const SortedIn& S, const StateIn& in, const StateOut& out,
+                                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ cellStart, int s) {
+    const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];
+    if (special_slot(k, S, in, out, order, s, P, V, O)) return;
+    const uint32_t cb = fbits(O.x);
+    const int cx = (int)(cb & 1023u), cy = (int)((cb >> 10) & 1023u), cz = (int)(cb >> 20);
+    Own o;
+    own_reset(o);
+    o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = 0.0f; o.prs = 0.0f;
+    const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
+    auto rows = [&](auto&& f) {
+        for (int r = 0; r < 9; ++r) {
+            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+            if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
+            const int rowBase = (nz * k.gy + ny) * k.gx;
+            const uint32_t qs = cellStart[rowBase + xlo], qe = cellStart[rowBase + xhi + 1];
+            for (uint32_t q = qs; q < qe; ++q) f(q);
+        }
+    };
+    rows([&](uint32_t q) { const float4 J = S.posI[q]; pair_density(k, o, J.x, J.y, J.z, (int32_t)-1); });
+    finish_density(k, o);
+    rows([&](uint32_t q) {
+        const float4 J = S.posI[q], JV = S.velP[q];
+        pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, (int32_t)((int)q != s ? -1 : 0));
+    });
+    integrate(k, o);
+    rows([&](uint32_t q) {
+        const float4 J = S.posI[q], JV = S.velP[q];
+        pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, (int32_t)((int)q != s ? -1 : 0));
+    });
+    const float foamOut = finish_particle(k, o, O.y);
+    store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ cellStart, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n || (uint32_t)s >= cellStart[k.numCells]) return;
+    sph_slow_one(k, S, in, out, order, cellStart, s);
+}
+
+// tuning knobs of k_sph_list (values measured best on MI355X)
+#ifndef SPH_LIST_MAXN
+#define SPH_LIST_MAXN 32     // list entries per target
+#endif
+#ifndef SPH_LIST_CAP
+#define SPH_LIST_CAP 96      // wave-private LDS window of one candidate row
+#endif
+#ifndef SPH_LIST_UNROLL
+#define SPH_LIST_UNROLL 3    // candidates per iteration of sweep 1
+#endif
+#ifndef SPH_LIST_LISTU
+#define SPH_LIST_LISTU 4     // list entries fetched together in sweeps 2 / 3
+#endif
+
+// k_sph_list: one target per lane over the sorted copy.  Sweep 1 walks the 9 contiguous (dy,dz) candidate rows once
+// (density + a list of everything within h of the entry position or within h + eps of the predicted new position);
+// the 64 targets of a wave are consecutive sorted slots, so their ranges of one row overlap heavily and the wave
+// stages their union in a wave-private LDS window with coalesced loads.  Sweeps 2 / 3 touch only the listed
+// neighbours.  Lists and windows are private to the thread / the wave: no __syncthreads.
+template <int MAXN, int UNROLL, int CAP>
+__global__ __launch_bounds__(kBlock) void k_sph_list(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n, int dbg,
+                                                     unsigned long long* __restrict__ stats) {
+    __shared__ uint16_t nl[MAXN + 1][kBlock];  // entry e of thread t: (run << 12) | offset inside the run; row MAXN absorbs writes of a full list
+    __shared__ uint32_t runLo[9][kBlock];      // first sorted slot of each of the 9 runs
+    __shared__ float4 stage[kBlock / 64][CAP];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    // XCD-aware block mapping: blocks b and b+8 run on the same XCD (round-robin dispatch); each XCD gets one contiguous
+    // eighth of the sorted order, so that its L2 holds only that part of the sorted copy.  Any mapping is correct.
+    const int nBlocks = (n + kBlock - 1) / kBlock, perXcd = (nBlocks + 7) >> 3;
+    const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
+    if (vb >= nBlocks) return;                               // whole block, uniformly
+    const int sRaw = vb * kBlock + tid;
+    const int bound = liveCount ? min(n, (int)*liveCount) : n;
+    bool live = sRaw < bound;                                // every lane stays to the end (the staging is a wave-wide cooperation)
+    const int s = live ? sRaw : max(bound - 1, 0);
+    const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];
+    if (live && special_slot(k, S, in, out, order, s, P, V, O)) live = false;
+    Own o;
+    own_reset(o);
+    o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = 0.0f; o.prs = 0.0f;
+    const uint32_t cb = fbits(O.x);
+    const int cx = (int)(cb & 1023u), cy = (int)((cb >> 10) & 1023u), cz = (int)(cb >> 20);
+    const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
+    // The list must hold every candidate within h of the ENTRY position (sweep 2) and of the position after this
+    // substep's integration (sweep 3).  The latter is predicted as entry + 0.995 v dt; what the forces of this substep
+    // add to it is covered by eps and checked after integrate().  (A search heuristic, not part of the arithmetic contract.)
+    const float eps = 0.08f * k.h;
+    const float hp = k.h + eps;
+    const float hp2 = hp * hp;
+    const float qx = fmaf(0.995f * o.vx, k.dt, o.px), qy = fmaf(0.995f * o.vy, k.dt, o.py), qz = fmaf(0.995f * o.vz, k.dt, o.pz);
+    uint32_t qs[9], qe[9];                                   // all 18 run bounds first (independent loads in flight)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+        const bool in = live && nz >= 0 && nz < k.gz && ny >= 0 && ny < k.gy;
+        const int rowBase = in ? (nz * k.gy + ny) * k.gx : 0;
+        const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
+        qs[r] = in ? a : 0u; qe[r] = in ? b : 0u;
+    }
+    int cnt = 0;
+    bool listOk = !(dbg & 1);
+    // ---- sweep 1: density over every candidate (branch-free: a rejected candidate adds +0), and the list ----
+    // The two distances (to the entry and to the predicted position) are one packed-fp32 chain (same rounding as dot3).
+    // The list is written unconditionally at the running count (a candidate that fails leaves the count alone).
+    const v2f PX = {o.px, qx}, PY = {o.py, qy}, PZ = {o.pz, qz};
+    auto visit = [&](const float4& J, bool valid, uint32_t off, int r) {
+        const float jx = valid ? J.x : 3.0e30f;             // an invalid slot (past the end of the run) is moved far away
+        const v2f dx = PX - jx, dyy = PY - J.y, dzz = PZ - J.z;
+        const v2f d2 = __builtin_elementwise_fma(dzz, dzz, __builtin_elementwise_fma(dyy, dyy, dx * dx));   // (r2, p2)
+        const float tt = fmaxf(k.h2 - d2.x, 0.0f);
+        o.dsum = fmaf(tt * tt, tt, o.dsum);
+        nl[min(cnt, MAXN)][tid] = (uint16_t)((r << 12) | (int)(off & 0xfffu));
+        cnt += (d2.x < k.h2 || d2.y < hp2) ? 1 : 0;
+    };
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t q0 = qs[r], q1 = qe[r];
+        runLo[r][tid] = q0;
+        if (q1 - q0 > 4096u) listOk = false;
+        // union of the wave's ranges of this row: lanes are consecutive sorted slots, so the row bases ascend with the
+        // lane and the union runs from the first non-empty lane's start to the last one's end; checked, with the direct
+        // loads as the fallback
+        const bool ne = q1 > q0;
+        const unsigned long long mne = __ballot(ne);
+        if (mne == 0ull) continue;                         // nobody has a candidate in this row
+        const int lf = __ffsll((long long)mne) - 1, ll = 63 - __clzll((long long)mne);
+        const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
+        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
+        const bool inside = !__any(ne && (q0 < A || q1 > B));
+        const bool staged = inside && B > A && (B - A) <= (uint32_t)CAP && !(dbg & 4);   // wave-uniform
+        if (staged) {
+            for (uint32_t i = (uint32_t)lane; i < B - A; i += 64u) stage[wv][i] = S.posI[A + i];
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t q = q0; q < q1; q += UNROLL) {
+                float4 J[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) J[u] = stage[wv][min(q + (uint32_t)u, q1 - 1u) - A];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u - q0, r);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            for (uint32_t q = q0; q < q1; q += UNROLL) {
+                float4 J[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) J[u] = S.posI[min(q + (uint32_t)u, q1 - 1u)];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u - q0, r);
+            }
+        }
+    }
+    listOk = listOk && cnt <= MAXN;
+    finish_density(k, o);
+
+    // every candidate again, in canonical order (lists that did not fit, sweep 3 after a long move)
+    auto full = [&](auto&& f) {
+        for (int r = 0; r < 9; ++r) {
+            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+            if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
+            const int rowBase = (nz * k.gy + ny) * k.gx;
+            const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
+            for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
+        }
+    };
+    auto listed = [&](auto&& f) {
+        for (int e = 0; e < cnt; e += SPH_LIST_LISTU) {
+            float4 J[SPH_LIST_LISTU], JV[SPH_LIST_LISTU];
+            int32_t ok[SPH_LIST_LISTU];
+#pragma unroll
+            for (int u = 0; u < SPH_LIST_LISTU; ++u) {
+                const uint32_t a = nl[min(e + u, cnt - 1)][tid];
+                const uint32_t q = runLo[a >> 12][tid] + (a & 0xfffu);
+                J[u] = S.posI[q]; JV[u] = S.velP[q];
+                ok[u] = (e + u < cnt && (int)q != s) ? -1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < SPH_LIST_LISTU; ++u) f(J[u], JV[u], ok[u]);
+        }
+    };
+    auto force_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
+    auto xsph_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
+    // ---- sweep 2 ----
+    if (listOk) listed(force_at); else full(force_at);
+    integrate(k, o);
+    // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
+    const float mx = o.px - qx, my = o.py - qy, mz = o.pz - qz;
+    const float lim = 0.98f * eps;
+    const bool near = dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2);
+    if (listOk && near) listed(xsph_at); else full(xsph_at);
+    const float foamOut = finish_particle(k, o, O.y);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+    if (dbg & 8) {   // diagnostics: [1] targets on an exact fallback sweep, [2] list entries, [4] lanes
+        const unsigned long long slowT = (unsigned long long)__popcll(__ballot(live && !(listOk && near)));
+        unsigned long long ents = (unsigned long long)(live ? cnt : 0);
+        for (int d = 32; d >= 1; d >>= 1) ents += (unsigned long long)__shfl_xor((int)ents, d, 64);
+        if (lane == 0) { atomicAdd(&stats[1], slowT); atomicAdd(&stats[2], ents & 0xffffffffull); atomicAdd(&stats[4], 64ull); }
+    }
+}
+
+}  // namespace sph

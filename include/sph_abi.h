@@ -111,14 +111,14 @@ typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHF
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
 enum {
-    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = k_sph_pair (default: two targets per lane, LDS-staged candidate rows, neighbour lists), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = k_sph_list (default: two targets per lane, LDS-staged candidate rows, neighbour lists), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
     SPH_OPT_GRAPH_LAUNCHES = 6,  /* read-only: number of graph replays so far */
     SPH_OPT_TIMING = 4,          /* hipEvents around kernels for sph_kernel_times(): 1 = every kernel, 2 = only the SPH pass */
     /* test / tuning hooks */
-    SPH_OPT_DEBUG = 100          /* test hooks of k_sph_pair -- bit 0: treat every neighbour list as overflowed, bit 1: treat every target as
+    SPH_OPT_DEBUG = 100          /* test hooks of k_sph_list -- bit 0: treat every neighbour list as overflowed, bit 1: treat every target as
                                     outside the list's slack (sweep-3 fallback), bit 2: treat every window as overflowed (whole wave falls
                                     back), bit 3: count fallbacks / list entries / staged candidates for sph_debug_counters */
 };
@@ -211,7 +211,7 @@ int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n);
  * particleCell[n] (binding 3) in the reference's cell indexing. Synchronises. */
 int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* particleCell, size_t n);
 int sph_sync(SphEngine* e);
-/* Diagnostic counters of k_sph_pair (SPH_OPT_DEBUG bit 3), summed over launches since the last reset:
+/* Diagnostic counters of k_sph_list (SPH_OPT_DEBUG bit 3), summed over launches since the last reset:
  * [0] waves that fell back as a whole, [1] targets recomputed by the exact fallback, [2] neighbour-list entries,
  * [3] candidates staged in LDS, [4] lanes (two targets each).  Never used on a timed path. */
 int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_sph_pair diagnostics (SPH_OPT_DEBUG bit 3): fallbacks, list entries and staged candidates per substep.
+"""k_sph_list diagnostics (SPH_OPT_DEBUG bit 3): fallbacks, list entries and staged candidates per substep.
 usage: pair_stats.py [config index=3] [substeps=5] [compare-with-slow 0|1]"""
 import importlib, json, os, sys
 import numpy as np
