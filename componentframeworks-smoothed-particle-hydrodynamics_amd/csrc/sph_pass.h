@@ -93,13 +93,16 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 
 // tuning knobs of k_sph_list (values measured best on MI355X)
 #ifndef SPH_LIST_MAXN
-#define SPH_LIST_MAXN 32     // list entries per target
+#define SPH_LIST_MAXN 29     // list entries per target
 #endif
 #ifndef SPH_LIST_CAP
 #define SPH_LIST_CAP 96      // wave-private LDS window of one candidate row
 #endif
 #ifndef SPH_LIST_UNROLL
 #define SPH_LIST_UNROLL 3    // candidates per iteration of sweep 1
+#endif
+#ifndef SPH_LIST_WAVES
+#define SPH_LIST_WAVES 5     // __launch_bounds__ minimum waves per SIMD (5: at most 96 VGPRs, 20 waves per CU with 32 KB of LDS per block)
 #endif
 #ifndef SPH_LIST_LISTU
 #define SPH_LIST_LISTU 4     // list entries fetched together in sweeps 2 / 3
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 // stages their union in a wave-private LDS window with coalesced loads.  Sweeps 2 / 3 touch only the listed
 // neighbours.  Lists and windows are private to the thread / the wave: no __syncthreads.
 template <int MAXN, int UNROLL, int CAP>
-__global__ __launch_bounds__(kBlock) void k_sph_list(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n, int dbg,
                                                      unsigned long long* __restrict__ stats) {
-    __shared__ uint16_t nl[MAXN + 1][kBlock];  // entry e of thread t: (run << 12) | offset inside the run; row MAXN absorbs writes of a full list
+    __shared__ uint16_t nl[MAXN + UNROLL][kBlock];   // entry e of thread t: (run << 12) | offset inside the run; rows >= MAXN absorb the writes of a full list
     __shared__ uint32_t runLo[9][kBlock];      // first sorted slot of each of the 9 runs
     __shared__ float4 stage[kBlock / 64][CAP];
     const int tid = threadIdx.x;
@@ -158,14 +161,29 @@ __global__ __launch_bounds__(kBlock) void k_sph_list(SimK k, SortedIn S, StateIn
     // The two distances (to the entry and to the predicted position) are one packed-fp32 chain (same rounding as dot3).
     // The list is written unconditionally at the running count (a candidate that fails leaves the count alone).
     const v2f PX = {o.px, qx}, PY = {o.py, qy}, PZ = {o.pz, qz};
-    auto visit = [&](const float4& J, bool valid, uint32_t off, int r) {
-        const float jx = valid ? J.x : 3.0e30f;             // an invalid slot (past the end of the run) is moved far away
-        const v2f dx = PX - jx, dyy = PY - J.y, dzz = PZ - J.z;
+    // one candidate: density term and the two-ball list test; returns 1 when the candidate belongs on the list
+    auto visit = [&](const float4& J) -> int {
+        const v2f dx = PX - J.x, dyy = PY - J.y, dzz = PZ - J.z;
         const v2f d2 = __builtin_elementwise_fma(dzz, dzz, __builtin_elementwise_fma(dyy, dyy, dx * dx));   // (r2, p2)
         const float tt = fmaxf(k.h2 - d2.x, 0.0f);
         o.dsum = fmaf(tt * tt, tt, o.dsum);
-        nl[min(cnt, MAXN)][tid] = (uint16_t)((r << 12) | (int)(off & 0xfffu));
-        cnt += (d2.x < k.h2 || d2.y < hp2) ? 1 : 0;
+        return (d2.x < k.h2 || d2.y < hp2) ? 1 : 0;
+    };
+    // candidates [m, m + UNROLL) of run r, all valid: the list rows are taken from one clamped running count
+    // (rows MAXN .. MAXN + UNROLL - 1 absorb the writes of a full list; cnt keeps counting for the overflow test)
+    auto group = [&](const float4 (&J)[UNROLL], uint32_t m, int r) {
+        int row = min(cnt, MAXN);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int p = visit(J[u]);
+            nl[row][tid] = (uint16_t)((r << 12) | (int)((m + (uint32_t)u) & 0xfffu));
+            row += p; cnt += p;
+        }
+    };
+    auto single = [&](const float4& J, uint32_t m, int r) {
+        const int p = visit(J);
+        nl[min(cnt, MAXN)][tid] = (uint16_t)((r << 12) | (int)(m & 0xfffu));
+        cnt += p;
     };
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
@@ -183,25 +201,29 @@ __global__ __launch_bounds__(kBlock) void k_sph_list(SimK k, SortedIn S, StateIn
         const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
         const bool inside = !__any(ne && (q0 < A || q1 > B));
         const bool staged = inside && B > A && (B - A) <= (uint32_t)CAP && !(dbg & 4);   // wave-uniform
+        const uint32_t len = q1 - q0;
+        uint32_t m = 0;
         if (staged) {
             for (uint32_t i = (uint32_t)lane; i < B - A; i += 64u) stage[wv][i] = S.posI[A + i];
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t q = q0; q < q1; q += UNROLL) {
+            const float4* __restrict__ wp = &stage[wv][ne ? q0 - A : 0u];
+            for (; m + UNROLL <= len; m += UNROLL) {       // full groups: no validity tests, immediate LDS offsets
                 float4 J[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) J[u] = stage[wv][min(q + (uint32_t)u, q1 - 1u) - A];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u - q0, r);
+                for (int u = 0; u < UNROLL; ++u) J[u] = wp[m + (uint32_t)u];
+                group(J, m, r);
             }
+            for (; m < len; ++m) single(wp[m], m, r);
             __builtin_amdgcn_wave_barrier();
         } else {
-            for (uint32_t q = q0; q < q1; q += UNROLL) {
+            const float4* __restrict__ gp = S.posI + q0;
+            for (; m + UNROLL <= len; m += UNROLL) {
                 float4 J[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) J[u] = S.posI[min(q + (uint32_t)u, q1 - 1u)];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) visit(J[u], q + (uint32_t)u < q1, q + (uint32_t)u - q0, r);
+                for (int u = 0; u < UNROLL; ++u) J[u] = gp[m + (uint32_t)u];
+                group(J, m, r);
             }
+            for (; m < len; ++m) single(gp[m], m, r);
         }
     }
     listOk = listOk && cnt <= MAXN;
