@@ -6,9 +6,10 @@
 One "step" = one DispatchCompute (ClearGrid -> BuildGrid -> SPHFluid -> OBBConstraints, the
 call of SPHFluid3D.cpp:431-522) over the whole particle set, inputs resident in HBM.
 N = 1 runs BASELINE.json configs[2] (4 194 304 particles, 128^3 grid, fp32), the
-configuration the metric is quoted on.  N > 1 runs the same per-GPU load weak-scaled along z
-(each rank owns a 128 x 128 x 128-cell slab with 4 194 304 particles; one-deep halo exchange
-per substep) -- see DESIGN.md "Multi-GPU".  Prints ONE JSON line on rank 0.
+configuration the metric is quoted on.  N > 1 runs BASELINE.json configs[4]: every rank owns a
+256 x 256 x 64-cell slab with 8 388 608 particles (weak scaling along z), OBBConstraints on,
+ApplyWaveImpulse every 16th substep, one-deep halo exchange per substep -- see DESIGN.md
+"Multi-GPU".  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -34,7 +35,8 @@ def parse():
     # few hundred substeps, which turns the run into a different, denser workload
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", help="auto | config2 | config3 | weak5 (BASELINE configs[4] slab)")
+    ap.add_argument("--workload", default="auto", help="auto (config3 at N = 1, weak5 at N > 1) | config2 | config3 | weak5 (BASELINE configs[4] slab)")
+    ap.add_argument("--settled-after", type=int, default=300, help="N = 1: after the timed run, continue the SAME run to this substep and record the settled regime (0 = skip)")
     ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 = k_sph_list (engine default), 1 = k_sph_slow (plain per-target sweeps)")
     ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,7 +112,7 @@ def main():
 
     wl = args.workload
     if wl == "auto":
-        wl = "config3"
+        wl = "config3" if args.gpus == 1 else "weak5"
     if wl == "config2":
         base = syn.CONFIGS[2]
     elif wl == "config3":
@@ -191,12 +193,34 @@ def main():
                 sim.set_option(pkg.SPH_OPT_TIMING, 2)
                 sim.kernel_times(reset=True)
                 for _ in range(3):
-                    sim.DispatchCompute(dt)
+                    step()
                 ms, cnt = sim.kernel_times(reset=True)["sph"]
                 alt[name] = round(ms / max(cnt, 1) * 1e3, 1)
             sim.set_option(pkg.SPH_OPT_TIMING, 0)
             sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
             breakdown["sph_pass_variants_after_run"] = alt
+
+    # The benchmark workload is not stationary (the column compresses under its own weight):
+    # the headline window above is the specified lattice state; this block records, untimed for `value`, what the
+    # SAME run costs once the fluid has settled into the compressed regime every long-running scene lives in.
+    settled = None
+    if args.gpus == 1 and args.settled_after > 0 and not args.no_breakdown:
+        done = wave["n"]
+        while wave["n"] < args.settled_after:
+            step()
+        ns = 20
+        sim.set_option(pkg.SPH_OPT_TIMING, 2)
+        sim.kernel_times(reset=True)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(ns):
+            step()
+        barrier()
+        tse = time.perf_counter() - ts
+        sms, scnt = sim.kernel_times(reset=True)["sph"]
+        sim.set_option(pkg.SPH_OPT_TIMING, 0)
+        settled = {"after_substeps": max(args.settled_after, done), "substeps_timed": ns, "sph_pass_us": round(sms / max(scnt, 1) * 1e3, 1),
+                   "ms_per_step": round(tse / ns * 1e3, 3), "particle_substeps_per_s": n_total * ns / tse}
 
     if rank != 0:
         if dist is not None:
@@ -210,31 +234,25 @@ def main():
     sph_avg_s = (sph_ms / max(sph_launches, 1)) * 1e-3
     alg_bytes = 164 * n_local + 4 * C_local          # SPHFluid pass, per launch
     achieved = alg_bytes / sph_avg_s / 1e9 if sph_avg_s > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and args.gpus == 1:          # the counter passes were taken on the N = 1 workload
+    # HBM traffic and VALU instruction counts are NOT measured in this run: they come from separate rocprofv3 --pmc
+    # passes over this same command (tools/profile_bench.sh), summarised for exactly the timed launches in
+    # profiles/r02_bench_counters.json; the line says so in traffic_source / valu.source.
+    traffic = traffic_source = None
+    valu = None
+    cpath = os.path.join(ROOT, "profiles", "r02_bench_counters.json")
+    kname = "k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list")[args.neighbor]
+    if os.path.exists(cpath) and args.gpus == 1:
         try:
-            tj = json.load(open(tpath))
-            if tj.get("workload") == wl and tj.get("neighbor") == args.neighbor:
-                traffic = tj.get("hbm_bytes_per_launch")
+            cj = json.load(open(cpath))
+            if cj.get("workload") == wl and cj.get("kernel") == kname:
+                traffic = cj.get("hbm_bytes_per_launch")
+                traffic_source = cj.get("source")
+                if cj.get("valu_wave_insts_per_launch") and sph_avg_s > 0:
+                    peak = 256 * 4 * 2.4e9 / 4.0          # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+                    valu = {"wave_insts_per_launch": cj["valu_wave_insts_per_launch"], "issue_peak_per_s": peak,
+                            "frac_of_issue_peak": cj["valu_wave_insts_per_launch"] / sph_avg_s / peak, "source": cj.get("source")}
         except Exception:
             traffic = None
-
-    # The pass is VALU-bound, not HBM-bound: next to the contract's HBM roofline, price the
-    # measured VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/) against the issue peak of the chip
-    # (256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz).
-    valu = None
-    vpath = os.path.join(ROOT, "profiles", "r01_bench_pmc_sq.json")
-    if traffic is not None and os.path.exists(vpath) and sph_avg_s > 0:
-        try:
-            vj = json.load(open(vpath))
-            kname = (None, "k_sph_slow", "k_sph_list")[args.neighbor]
-            insts = next(v["SQ_INSTS_VALU"]["mean"] for k, v in vj.items() if kname + "<" in k or k.endswith(kname))
-            peak = 256 * 4 * 2.4e9 / 4.0
-            valu = {"wave_insts_per_launch": insts, "issue_peak_per_s": peak, "frac_of_issue_peak": insts / sph_avg_s / peak,
-                    "source": "profiles/r01_bench_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU, first 15 launches)"}
-        except Exception:
-            valu = None
 
     out = {
         "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-substeps/s",
@@ -250,11 +268,14 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": ("k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list")[args.neighbor]),
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
+            "window": {"kernel": kname, "first_launch": args.warmup, "launches": int(sph_launches),
+                       "note": "0-based index among this kernel's launches of the run; profiles/r02_bench_kernel_window.json holds the rocprofv3 --kernel-trace average of exactly these launches"},
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },
         "kernels_us_per_substep": breakdown,
+        "settled": settled,
         "valu": valu,
     }
     if not args.no_cpu_baseline and args.gpus == 1:

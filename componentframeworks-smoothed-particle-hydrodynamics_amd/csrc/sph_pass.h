@@ -226,44 +226,61 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
             for (; m < len; ++m) single(gp[m], m, r);
         }
     }
-    listOk = listOk && cnt <= MAXN;
+    listOk = (listOk && cnt <= MAXN) || !live;          // lanes without a target never take a fallback
     finish_density(k, o);
 
-    // every candidate again, in canonical order (lists that did not fit, sweep 3 after a long move)
-    auto full = [&](auto&& f) {
-        for (int r = 0; r < 9; ++r) {
-            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
-            if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
-            const int rowBase = (nz * k.gy + ny) * k.gx;
-            const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
-            for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
-        }
-    };
-    auto listed = [&](auto&& f) {
-        for (int e = 0; e < cnt; e += SPH_LIST_LISTU) {
+    // walk the first `count` list entries, SPH_LIST_LISTU loads in flight
+    auto listed = [&](int count, auto&& f) {
+        for (int e = 0; e < count; e += SPH_LIST_LISTU) {
             float4 J[SPH_LIST_LISTU], JV[SPH_LIST_LISTU];
             int32_t ok[SPH_LIST_LISTU];
 #pragma unroll
             for (int u = 0; u < SPH_LIST_LISTU; ++u) {
-                const uint32_t a = nl[min(e + u, cnt - 1)][tid];
+                const uint32_t a = nl[min(e + u, count - 1)][tid];
                 const uint32_t q = runLo[a >> 12][tid] + (a & 0xfffu);
                 J[u] = S.posI[q]; JV[u] = S.velP[q];
-                ok[u] = (e + u < cnt && (int)q != s) ? -1 : 0;
+                ok[u] = (e + u < count && (int)q != s) ? -1 : 0;
             }
 #pragma unroll
             for (int u = 0; u < SPH_LIST_LISTU; ++u) f(J[u], JV[u], ok[u]);
         }
     };
+    // Exact fallback of a sweep (a list that did not fit: compressed fluid; sweep 3 after a long move): every
+    // candidate again, in canonical order, in CHUNKS -- candidates within h of (cpx, cpy, cpz) are collected into the
+    // list until some lane's list is full, then the wave walks what it has and starts over.  The accumulators see
+    // the same operations in the same order as one uninterrupted sweep (a candidate outside h adds +0 either way).
+    auto chunked = [&](float cpx, float cpy, float cpz, auto&& f) {
+        int c = 0;
+        for (int r = 0; r < 9; ++r) {
+            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+            if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
+            const int rowBase = (nz * k.gy + ny) * k.gx;
+            const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
+            if (b - a > 4096u) {                               // offsets beyond the entry format: plain sweep of this run
+                listed(c, f); c = 0;
+                for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
+                continue;
+            }
+            for (uint32_t q = a; q < b; ++q) {
+                const float4 J = S.posI[q];
+                const float dx = cpx - J.x, dy = cpy - J.y, dz = cpz - J.z;
+                nl[c][tid] = (uint16_t)((r << 12) | (int)(q - a));
+                c += dot3(dx, dy, dz, dx, dy, dz) < k.h2 ? 1 : 0;
+                if (__any(c >= MAXN)) { listed(c, f); c = 0; }
+            }
+        }
+        listed(c, f);
+    };
     auto force_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
     auto xsph_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
     // ---- sweep 2 ----
-    if (listOk) listed(force_at); else full(force_at);
+    if (listOk) listed(cnt, force_at); else chunked(o.px, o.py, o.pz, force_at);
     integrate(k, o);
     // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
     const float mx = o.px - qx, my = o.py - qy, mz = o.pz - qz;
     const float lim = 0.98f * eps;
-    const bool near = dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2);
-    if (listOk && near) listed(xsph_at); else full(xsph_at);
+    const bool near = (dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2)) || !live;
+    if (listOk && near) listed(cnt, xsph_at); else chunked(o.px, o.py, o.pz, xsph_at);
     const float foamOut = finish_particle(k, o, O.y);
     if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
     if (dbg & 8) {   // diagnostics: [1] targets on an exact fallback sweep, [2] list entries, [4] lanes

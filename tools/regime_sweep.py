@@ -2,7 +2,7 @@
 """SPH-pass time along the trajectory of a bench workload (the fluid column of configs[2] collapses,
 DESIGN.md section 6).  The passes are bit-identical, so switching between them does not perturb the run.
 usage: regime_sweep.py [config index=3] [last step=300] [stride=25] [passes, e.g. 2,0,1]
-pass ids: 2 sorted gather, 0 tiled (+ slow queue), 1 plain gather"""
+pass ids: 2 k_sph_list, 1 k_sph_slow"""
 import importlib
 import json
 import os
@@ -16,7 +16,7 @@ syn = pkg.synthetic
 ci = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 stride = int(sys.argv[3]) if len(sys.argv) > 3 else 25
-kinds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2,0,1").split(",")]
+kinds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2").split(",")]
 cfg = syn.CONFIGS[ci]
 sp = pkg.default_params(**syn.params_fields(cfg))
 rec, _ = syn.make_particles(cfg)
@@ -42,7 +42,7 @@ step = 0
 while step <= last:
     row = {"step": step}
     for kind in kinds:
-        row[{2: "gather2", 0: "tile+slow", 1: "gather"}[kind] + "_us"] = timed(kind)
+        row[{2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
         step += REPS
     print(json.dumps(row), flush=True)
     select(2)

@@ -4,6 +4,8 @@
     rocpd_summary.py stats  <results.db> <out.csv>            # --kernel-trace --stats run -> per-kernel table
     rocpd_summary.py pmc    <results.db> <out.json> [substr]  # --pmc run -> mean counter values per kernel
     rocpd_summary.py traffic <fetch.db> <write.db> <kernel substr> <workload> <neighbor> <out.json>
+    rocpd_summary.py window <stats.db> <kernel substr> <first launch> <count> <out.json>     # exactly bench.py's timed launches
+    rocpd_summary.py bench-counters <fetch.db> <write.db> <valu.db> <kernel> <first> <count> <workload> <source> <out.json>
 
 traffic: HBM bytes per launch of the dominant kernel as /opt/skills/guides/MI355X_MICROARCH.md prescribes
 (FETCH_SIZE / WRITE_SIZE from separate passes, KiB units; on gfx950 FETCH_SIZE tallies 128-byte requests at
@@ -37,8 +39,46 @@ def pmc_means(db, substr=""):
     return res
 
 
+def window_stats(db, substr, first, count):
+    """Durations (us) of launches [first, first + count) of the kernel whose name contains substr, in start order."""
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, start, end from kernels order by start").fetchall()
+    d = [(e - s) / 1e3 for n, s, e in rows if substr in n]
+    w = d[first:first + count]
+    return {"kernel": substr, "launches_in_run": len(d), "first_launch": first, "launches": len(w),
+            "average_us": sum(w) / max(len(w), 1), "min_us": min(w) if w else None, "max_us": max(w) if w else None,
+            "average_us_all_launches": sum(d) / max(len(d), 1)}
+
+
+def window_counter(db, substr, counter, first, count):
+    """Mean of a PMC counter over launches [first, first + count) of the kernel (dispatch order)."""
+    con = sqlite3.connect(db)
+    q = "select kernel_name, dispatch_id, value from counters_collection where counter_name = ? order by dispatch_id"
+    v = [val for name, did, val in con.execute(q, (counter,)) if substr in name]
+    w = v[first:first + count]
+    return {"mean": sum(w) / max(len(w), 1), "launches": len(w), "launches_in_run": len(v)}
+
+
 def main():
     mode = sys.argv[1]
+    if mode == "window":          # window <stats.db> <kernel substr> <first> <count> <out.json>
+        res = window_stats(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
+        json.dump(res, open(sys.argv[6], "w"), indent=1)
+        print(json.dumps(res))
+        return
+    if mode == "bench-counters":  # bench-counters <fetch.db> <write.db> <valu.db> <kernel> <first> <count> <workload> <source text> <out.json>
+        fdb, wdb, vdb, kernel, first, count, workload, source, out = sys.argv[2:11]
+        first, count = int(first), int(count)
+        f = window_counter(fdb, kernel, "FETCH_SIZE", first, count)
+        w = window_counter(wdb, kernel, "WRITE_SIZE", first, count)
+        v = window_counter(vdb, kernel, "SQ_INSTS_VALU", first, count)
+        res = {"workload": workload, "kernel": kernel, "first_launch": first, "launches": count,
+               "fetch_size_kib_raw": f["mean"], "write_size_kib_raw": w["mean"],
+               "correction": "read side doubled (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); write side as reported",
+               "hbm_bytes_per_launch": (2.0 * f["mean"] + w["mean"]) * 1024.0, "valu_wave_insts_per_launch": v["mean"], "source": source}
+        json.dump(res, open(out, "w"), indent=1)
+        print(json.dumps(res))
+        return
     if mode == "stats":
         for r in stats(sys.argv[2], sys.argv[3])[:6]:
             print(r)
