@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 
 // tuning knobs of k_sph_list (values measured best on MI355X)
 #ifndef SPH_LIST_MAXN
-#define SPH_LIST_MAXN 29     // list entries per target
+#define SPH_LIST_MAXN 47     // list entries per target
 #endif
 #ifndef SPH_LIST_CAP
 #define SPH_LIST_CAP 96      // wave-private LDS window of one candidate row
@@ -103,6 +103,9 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 #endif
 #ifndef SPH_LIST_WAVES
 #define SPH_LIST_WAVES 5     // __launch_bounds__ minimum waves per SIMD (5: at most 96 VGPRs, 20 waves per CU with 32 KB of LDS per block)
+#endif
+#ifndef SPH_LIST_EPS
+#define SPH_LIST_EPS 0.06f  // slack of the list around the predicted position, in units of h
 #endif
 #ifndef SPH_LIST_LISTU
 #define SPH_LIST_LISTU 4     // list entries fetched together in sweeps 2 / 3
@@ -117,8 +120,8 @@ template <int MAXN, int UNROLL, int CAP>
 __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n, int dbg,
                                                      unsigned long long* __restrict__ stats) {
-    __shared__ uint16_t nl[MAXN + UNROLL][kBlock];   // entry e of thread t: (run << 12) | offset inside the run; rows >= MAXN absorb the writes of a full list
-    __shared__ uint32_t runLo[9][kBlock];      // first sorted slot of each of the 9 runs
+    __shared__ uint16_t nl[MAXN + UNROLL][kBlock];   // entry e of thread t: (row << 12) | (slot - rowA[row]); rows >= MAXN absorb the writes of a full list
+    __shared__ uint32_t rowA[kBlock / 64][12];       // per wave: first slot of the wave's union of each of the 9 candidate rows
     __shared__ float4 stage[kBlock / 64][CAP];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -142,10 +145,11 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
     // The list must hold every candidate within h of the ENTRY position (sweep 2) and of the position after this
     // substep's integration (sweep 3).  The latter is predicted as entry + 0.995 v dt; what the forces of this substep
     // add to it is covered by eps and checked after integrate().  (A search heuristic, not part of the arithmetic contract.)
-    const float eps = 0.08f * k.h;
+    const float eps = SPH_LIST_EPS * k.h;
     const float hp = k.h + eps;
     const float hp2 = hp * hp;
-    const float qx = fmaf(0.995f * o.vx, k.dt, o.px), qy = fmaf(0.995f * o.vy, k.dt, o.py), qz = fmaf(0.995f * o.vz, k.dt, o.pz);
+    const float qx = fmaf(0.995f * fmaf(k.gravx, k.dt, o.vx), k.dt, o.px), qy = fmaf(0.995f * fmaf(k.gravy, k.dt, o.vy), k.dt, o.py),
+                qz = fmaf(0.995f * fmaf(k.gravz, k.dt, o.vz), k.dt, o.pz);      // free-flight prediction
     uint32_t qs[9], qe[9];                                   // all 18 run bounds first (independent loads in flight)
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
@@ -171,37 +175,42 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
     };
     // candidates [m, m + UNROLL) of run r, all valid: the list rows are taken from one clamped running count
     // (rows MAXN .. MAXN + UNROLL - 1 absorb the writes of a full list; cnt keeps counting for the overflow test)
-    auto group = [&](const float4 (&J)[UNROLL], uint32_t m, int r) {
+    auto group = [&](const float4 (&J)[UNROLL], uint32_t ebase) {   // ebase = (row << 12) | (slot of J[0] - rowA[row])
         int row = min(cnt, MAXN);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int p = visit(J[u]);
-            nl[row][tid] = (uint16_t)((r << 12) | (int)((m + (uint32_t)u) & 0xfffu));
+            nl[row][tid] = (uint16_t)(ebase + (uint32_t)u);
             row += p; cnt += p;
         }
     };
-    auto single = [&](const float4& J, uint32_t m, int r) {
+    auto single = [&](const float4& J, uint32_t e) {
         const int p = visit(J);
-        nl[min(cnt, MAXN)][tid] = (uint16_t)((r << 12) | (int)(m & 0xfffu));
+        nl[min(cnt, MAXN)][tid] = (uint16_t)e;
         cnt += p;
     };
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         const uint32_t q0 = qs[r], q1 = qe[r];
-        runLo[r][tid] = q0;
-        if (q1 - q0 > 4096u) listOk = false;
         // union of the wave's ranges of this row: lanes are consecutive sorted slots, so the row bases ascend with the
-        // lane and the union runs from the first non-empty lane's start to the last one's end; checked, with the direct
-        // loads as the fallback
+        // lane and the union runs from the first non-empty lane's start to the last one's end (two readlanes; checked,
+        // with wave reductions as the fallback)
         const bool ne = q1 > q0;
         const unsigned long long mne = __ballot(ne);
         if (mne == 0ull) continue;                         // nobody has a candidate in this row
         const int lf = __ffsll((long long)mne) - 1, ll = 63 - __clzll((long long)mne);
-        const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
-        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
-        const bool inside = !__any(ne && (q0 < A || q1 > B));
-        const bool staged = inside && B > A && (B - A) <= (uint32_t)CAP && !(dbg & 4);   // wave-uniform
+        uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
+        uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
+        if (__any(ne && (q0 < A || q1 > B))) {             // not ascending (cannot happen for consecutive slots; kept exact anyway)
+            uint32_t lo = ne ? q0 : 0xffffffffu, hi = ne ? q1 : 0u;
+            for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); }
+            A = lo; B = hi;
+        }
+        if (lane == 0) rowA[wv][r] = A;
+        if (B - A > 4095u) listOk = false;                 // offsets beyond the entry format (wave-uniform)
+        const bool staged = (B - A) <= (uint32_t)CAP && !(dbg & 4);   // wave-uniform
         const uint32_t len = q1 - q0;
+        const uint32_t ebase = ((uint32_t)r << 12) | ((ne ? q0 - A : 0u) & 0xfffu);
         uint32_t m = 0;
         if (staged) {
             for (uint32_t i = (uint32_t)lane; i < B - A; i += 64u) stage[wv][i] = S.posI[A + i];
@@ -211,9 +220,9 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
                 float4 J[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) J[u] = wp[m + (uint32_t)u];
-                group(J, m, r);
+                group(J, ebase + m);
             }
-            for (; m < len; ++m) single(wp[m], m, r);
+            for (; m < len; ++m) single(wp[m], ebase + m);
             __builtin_amdgcn_wave_barrier();
         } else {
             const float4* __restrict__ gp = S.posI + q0;
@@ -221,11 +230,12 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
                 float4 J[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) J[u] = gp[m + (uint32_t)u];
-                group(J, m, r);
+                group(J, ebase + m);
             }
-            for (; m < len; ++m) single(gp[m], m, r);
+            for (; m < len; ++m) single(gp[m], ebase + m);
         }
     }
+    __builtin_amdgcn_wave_barrier();                       // rowA written by lane 0, read by every lane below
     listOk = (listOk && cnt <= MAXN) || !live;          // lanes without a target never take a fallback
     finish_density(k, o);
 
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
 #pragma unroll
             for (int u = 0; u < SPH_LIST_LISTU; ++u) {
                 const uint32_t a = nl[min(e + u, count - 1)][tid];
-                const uint32_t q = runLo[a >> 12][tid] + (a & 0xfffu);
+                const uint32_t q = rowA[wv][a >> 12] + (a & 0xfffu);
                 J[u] = S.posI[q]; JV[u] = S.velP[q];
                 ok[u] = (e + u < count && (int)q != s) ? -1 : 0;
             }
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
             if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
             const int rowBase = (nz * k.gy + ny) * k.gx;
             const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
-            if (b - a > 4096u) {                               // offsets beyond the entry format: plain sweep of this run
+            const uint32_t base = rowA[wv][r];                 // <= a: the wave's union of this row starts at or before this lane's run
+            if (b - base > 4095u || base > a) {                // offsets beyond the entry format: plain sweep of this run
                 listed(c, f); c = 0;
                 for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
                 continue;
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
             for (uint32_t q = a; q < b; ++q) {
                 const float4 J = S.posI[q];
                 const float dx = cpx - J.x, dy = cpy - J.y, dz = cpz - J.z;
-                nl[c][tid] = (uint16_t)((r << 12) | (int)(q - a));
+                nl[c][tid] = (uint16_t)((r << 12) | (int)(q - base));
                 c += dot3(dx, dy, dz, dx, dy, dz) < k.h2 ? 1 : 0;
                 if (__any(c >= MAXN)) { listed(c, f); c = 0; }
             }
@@ -287,7 +298,8 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
         const unsigned long long slowT = (unsigned long long)__popcll(__ballot(live && !(listOk && near)));
         unsigned long long ents = (unsigned long long)(live ? cnt : 0);
         for (int d = 32; d >= 1; d >>= 1) ents += (unsigned long long)__shfl_xor((int)ents, d, 64);
-        if (lane == 0) { atomicAdd(&stats[1], slowT); atomicAdd(&stats[2], ents & 0xffffffffull); atomicAdd(&stats[4], 64ull); }
+        const unsigned long long ovf = (unsigned long long)__popcll(__ballot(live && !listOk)), far = (unsigned long long)__popcll(__ballot(live && listOk && !near));
+        if (lane == 0) { atomicAdd(&stats[1], slowT); atomicAdd(&stats[2], ents & 0xffffffffull); atomicAdd(&stats[4], 64ull); atomicAdd(&stats[5], ovf); atomicAdd(&stats[6], far); atomicAdd(&stats[7], slowT ? 1ull : 0ull); }
     }
 }
 

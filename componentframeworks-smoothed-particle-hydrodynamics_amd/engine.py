@@ -81,7 +81,7 @@ ABI_SYMBOLS = (
     "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
 )
 # sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_list, summed over launches
-STAMP_NAMES = ("slow_waves", "slow_targets", "list_entries", "window_candidates", "lanes", "r5", "r6", "r7")
+STAMP_NAMES = ("slow_waves", "slow_targets", "list_entries", "window_candidates", "lanes", "overflow_targets", "far_targets", "waves_with_fallback")
 
 
 class SphError(RuntimeError):

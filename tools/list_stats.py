@@ -23,8 +23,8 @@ for s in range(steps):
     f.DispatchCompute()
     c = f.debug_counters(reset=True)
     lanes = max(c["lanes"], 1)
-    row = {"substep": s, "slow_waves": c["slow_waves"], "slow_targets": c["slow_targets"], "entries_per_lane": round(c["list_entries"] / lanes, 2),
-           "window_per_wave": round(c["window_candidates"] / (lanes / 64), 1), "fast_waves": lanes // 64}
+    row = {"substep": s, "fallback_targets": c["slow_targets"], "overflow": c["overflow_targets"], "far": c["far_targets"],
+           "waves_with_fallback": c["waves_with_fallback"], "waves": lanes // 64, "entries_per_lane": round(c["list_entries"] / lanes, 2)}
     if g is not None:
         g.DispatchCompute()
         a, b = f.download(), g.download()
