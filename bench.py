@@ -131,7 +131,7 @@ def main():
         sim = pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream)
         n_local, n_total = len(rec), len(rec)
     else:
-        sim = halo.SlabSimulation.from_config(cfg, sp, rank, world, stream=stream, transport="direct" if backend == "nccl" else "host")
+        sim = halo.SlabSimulation.from_config(cfg, sp, rank, world, stream=stream, transport="rccl" if backend == "nccl" else "host")
         rec = None
         n_local, n_total = sim.num_owned(), cfg.n
     sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)

@@ -103,7 +103,9 @@ struct SphEngine {
     // z-slab (multi-GPU) mode: this engine owns global cell layers [z0, z1) and keeps one ghost layer per side
     bool slab = false;
     int z0 = 0, z1 = 0, hasLo = 0, hasHi = 0;
-    size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count
+    size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count (= cap once the async exchange is used)
+    sph::SlabRec* d_face[4] = {nullptr, nullptr, nullptr, nullptr};   // engine-owned halo buffers: send lo / hi, recv lo / hi ((faceCap + 1) records, record 0 = header)
+    uint32_t faceCap = 0;
     SphFountain fountain{};                 // fountain* members (SPHFluid3D.h:161-168)
     float4 *d_sPos = nullptr, *d_sVel = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state (gather2 pass)
     size_t sortedCap = 0;
@@ -168,7 +170,8 @@ void free_particle_buffers(SphEngine* e) {
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
-    dev_free(e->d_slabCnt); dev_free(e->d_shapeTab); dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
+    dev_free(e->d_slabCnt); for (auto& f : e->d_face) dev_free(f);
+    e->faceCap = 0; dev_free(e->d_shapeTab); dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     e->graphs.clear();
     dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
@@ -194,7 +197,7 @@ int alloc_particle_buffers(SphEngine* e, size_t n) {
     if ((rc = dev_alloc(&e->d_slotOf, n))) return rc;
     if ((rc = dev_alloc(&e->d_order, n))) return rc;
     if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
-    if ((rc = dev_alloc(&e->d_slabCnt, 4))) return rc;
+    if ((rc = dev_alloc(&e->d_slabCnt, 8))) return rc;
     e->cap = n;
     return SPH_OK;
 }
@@ -273,7 +276,8 @@ int build_grid(SphEngine* e, const SimK& k) {
     }
     if (n) {
         Timed t(e, SPH_K_BIN);
-        hipLaunchKernelGGL(k_bin, dim3(nb), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellCount, n);
+        hipLaunchKernelGGL(k_bin, dim3(nb), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellCount, n,
+                           e->slab ? e->d_slabCnt + 2 : (const uint32_t*)nullptr);
     }
     {
         Timed t(e, SPH_K_SCAN);
@@ -394,6 +398,7 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         hipLaunchKernelGGL(k_obb_ext, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->shapeTab, out.pos, out.vel, live, n);
     }
     if (e->fountain.fountainMode) {                                         // :519, :526-544
+        if (e->slab) return fail(SPH_ERR_STATE, "fountainMode on a z-slab engine: recycled particles jump across slabs (single-GPU engines only)");
         if (n) {
             float half[3];
             effective_half(e->params, half);
@@ -878,6 +883,8 @@ int sph_create_slab(SphEngine** out, const SphParticle* particles, const uint32_
     if ((!particles || !ids) && n) return fail(SPH_ERR_ARG, "null particles / ids");
     if (z1 <= z0 || z0 < 0) return fail(SPH_ERR_ARG, "bad slab range [%d, %d)", z0, z1);
     if (capacity < n) return fail(SPH_ERR_ARG, "capacity %zu < %zu particles", capacity, n);
+    if (hasLo && hasHi && z1 - z0 < 2)
+        return fail(SPH_ERR_ARG, "an inner slab needs at least 2 cell layers (a migrant from below would have to become the upper neighbour's ghost within the same substep)");
     SphEngine* e = nullptr;
     int rc = create_common(out, params, stream, &e);
     if (rc) return rc;
@@ -895,7 +902,7 @@ int sph_create_slab(SphEngine** out, const SphParticle* particles, const uint32_
         if (er != hipSuccess) return cleanup(fail(SPH_ERR_HIP, "upload failed: %s", hipGetErrorString(er)));
         hipLaunchKernelGGL(k_slab_import, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, e->d_aos, d_ids, e->d_pos[0], e->d_vel[0], e->d_rp[0], e->d_foam[0], (int)n);
     }
-    const uint32_t init[4] = {0u, 0u, (uint32_t)n, 0u};
+    const uint32_t init[8] = {0u, 0u, (uint32_t)n, 0u, 0u, 0u, 0u, 0u};
     hipError_t er = hipMemcpyAsync(e->d_slabCnt, init, sizeof(init), hipMemcpyHostToDevice, e->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
     if (er != hipSuccess) return cleanup(fail(SPH_ERR_HIP, "slab init failed: %s", hipGetErrorString(er)));
@@ -973,6 +980,189 @@ int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nO
     if (er != hipSuccess) return fail(SPH_ERR_HIP, "slab download failed: %s", hipGetErrorString(er));
     *nOut = cnt;
     return SPH_OK;
+}
+
+// ---- exchange without host round trips (device-side counts) + RCCL transport -------------------------------------
+int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    if (faceCap == 0) return fail(SPH_ERR_ARG, "face capacity must be > 0");
+    if (e->faceCap == faceCap && e->d_face[0]) return SPH_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc;
+    for (int i = 0; i < 4; ++i) {
+        dev_free(e->d_face[i]);
+        if ((rc = dev_alloc(&e->d_face[i], (size_t)faceCap + 1))) return rc;
+        HIP_TRY(hipMemsetAsync(e->d_face[i], 0, sizeof(SlabRec), e->stream));      // empty header
+    }
+    e->faceCap = faceCap;
+    return SPH_OK;
+}
+int sph_slab_face_buffer(SphEngine* e, int which, void** devPtr) {
+    if (!e || !devPtr) return fail(SPH_ERR_ARG, "null argument");
+    if (which < 0 || which > 3 || !e->d_face[which]) return fail(SPH_ERR_STATE, "no face buffers: call sph_slab_alloc_faces first");
+    *devPtr = e->d_face[which];
+    return SPH_OK;
+}
+int sph_slab_pack_async(SphEngine* e) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
+    sph::compute_grid_extents(e->params, e->grid);
+    SimK k;
+    make_simk(e->params, e->grid, e->params.param_timeStep, k);
+    e->nSlots = e->cap;                                     // from now on only a launch bound: slabCnt[2] counts the slots in use
+    HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 2 * sizeof(uint32_t), e->stream));
+    {
+        Timed t(e, SPH_K_OTHER);
+        hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->cap)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
+                           e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], (int)e->cap,
+                           e->d_face[0] + 1, e->d_face[1] + 1, e->faceCap, e->faceCap, e->d_slabCnt);
+        hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, e->hasLo ? e->d_face[0] : (SlabRec*)nullptr,
+                           e->hasHi ? e->d_face[1] : (SlabRec*)nullptr, e->faceCap, e->faceCap);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    const SlabRec* lo = e->hasLo ? (const SlabRec*)recvLo : nullptr;
+    const SlabRec* hi = e->hasHi ? (const SlabRec*)recvHi : nullptr;
+    if ((e->hasLo && !lo) || (e->hasHi && !hi)) return fail(SPH_ERR_ARG, "missing receive buffer");
+    const int c = e->cur;
+    e->nSlots = e->cap;
+    Timed t(e, SPH_K_OTHER);
+    if (lo) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, e->stream, lo, (const SlabRec*)nullptr, recvCap,
+                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_slabCnt, (uint32_t)e->cap);
+    if (hi) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, e->stream, hi, lo, recvCap,
+                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_slabCnt, (uint32_t)e->cap);
+    hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, lo, hi, (uint32_t)e->cap);
+    HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+int sph_slab_status(SphEngine* e, uint32_t out[5]) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    uint32_t host[8];
+    HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 5; ++i) out[i] = host[i];
+    if (host[4] & 1u) return fail(SPH_ERR_CAPACITY, "halo send buffer overflowed (%u / %u records for a capacity of %u)", host[0], host[1], e->faceCap);
+    if (host[4] & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
+    return SPH_OK;
+}
+
+}  // extern "C"
+
+// RCCL is loaded at run time (dlopen): the library has no link-time dependency on it, and a host without RCCL still loads
+// the engine (the exchange then fails with a message).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return SPH_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(SPH_ERR_HIP, "RCCL not available: %s", dlerror());
+    Rccl r;
+    r.lib = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        dlclose(h);
+        return fail(SPH_ERR_HIP, "RCCL library lacks a required entry point");
+    }
+    g_rccl = r;
+    return SPH_OK;
+}
+#define NCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess) return fail(SPH_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
+    } while (0)
+}  // namespace
+
+struct SphComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int sph_comm_unique_id(void* out128) {
+    if (!out128) return fail(SPH_ERR_ARG, "null argument");
+    static_assert(sizeof(ncclUniqueId) == SPH_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    int rc;
+    if ((rc = rccl_load())) return rc;
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    std::memcpy(out128, &id, sizeof(id));
+    return SPH_OK;
+}
+int sph_comm_create(SphComm** out, const void* id128, int rank, int world) {
+    if (!out || !id128) return fail(SPH_ERR_ARG, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SPH_ERR_ARG, "bad rank %d of %d", rank, world);
+    int rc;
+    if ((rc = rccl_load())) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    SphComm* c = new SphComm();
+    c->rank = rank; c->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);       // one rank per process, on the current HIP device
+    if (r != ncclSuccess) { delete c; return fail(SPH_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    *out = c;
+    return SPH_OK;
+}
+int sph_comm_destroy(SphComm* c) {
+    if (!c) return SPH_OK;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return SPH_OK;
+}
+// One halo exchange of a substep: pack -> one grouped ncclSend / ncclRecv per z-neighbour (fixed-size messages: header
+// record + faceCap payload records) -> unpack, all enqueued on the engine's stream: no host synchronisation, and the
+// stream order makes the unpack wait for the receives and the next pack wait for the sends.
+int sph_slab_exchange(SphEngine* e, SphComm* c) {
+    if (!e || !c) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
+    if ((e->hasLo && c->rank == 0) || (e->hasHi && c->rank == c->world - 1)) return fail(SPH_ERR_ARG, "slab neighbours do not match rank %d of %d", c->rank, c->world);
+    int rc;
+    if ((rc = sph_slab_pack_async(e))) return rc;
+    const size_t bytes = ((size_t)e->faceCap + 1) * sizeof(SlabRec);
+    if (e->hasLo || e->hasHi) {
+        NCCL_TRY(g_rccl.GroupStart());
+        ncclResult_t r = ncclSuccess;
+        if (e->hasLo) {
+            r = g_rccl.Send(e->d_face[0], bytes, ncclUint8, c->rank - 1, c->comm, e->stream);
+            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2], bytes, ncclUint8, c->rank - 1, c->comm, e->stream);
+        }
+        if (r == ncclSuccess && e->hasHi) {
+            r = g_rccl.Send(e->d_face[1], bytes, ncclUint8, c->rank + 1, c->comm, e->stream);
+            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[3], bytes, ncclUint8, c->rank + 1, c->comm, e->stream);
+        }
+        ncclResult_t g = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return fail(SPH_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
+        if (g != ncclSuccess) return fail(SPH_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(g));
+    }
+    return sph_slab_unpack_async(e, e->d_face[2], e->d_face[3], e->faceCap);
 }
 
 int sph_sync(SphEngine* e) {

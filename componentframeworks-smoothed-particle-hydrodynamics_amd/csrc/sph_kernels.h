@@ -48,12 +48,15 @@ __global__ __launch_bounds__(kBlock) void k_import(const SphParticle* __restrict
 // lanes: each run of equal cells inside a wave issues ONE returning atomic (run leader) and
 // hands out consecutive slots, instead of one contended atomic per particle.
 __global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict__ pos, uint32_t* __restrict__ cellOf,
-                                                uint32_t* __restrict__ slotOf, uint32_t* __restrict__ cellCount, int n) {
+                                                uint32_t* __restrict__ slotOf, uint32_t* __restrict__ cellCount, int n,
+                                                const uint32_t* __restrict__ slotsInUse) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool inRange = i < n;
-    uint32_t cell = 0xFFFFFFFFu;              // also the key of dead slots (z-slab mode): they get no slot
-    if (inRange) {
+    // z-slab mode without host round trips: n is only a launch bound, the slots that hold data are counted on the device
+    const bool used = inRange && (!slotsInUse || (uint32_t)i < *slotsInUse);
+    uint32_t cell = 0xFFFFFFFFu;              // also the key of dead / unused slots (z-slab mode): they get no slot
+    if (used) {
         const float4 p = pos[i];
         const int cx = cell_axis(p.x, k.gminx, k.cellSize, k.gx);
         const int cy = cell_axis(p.y, k.gminy, k.cellSize, k.gy);
@@ -669,6 +672,39 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
     vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
+}
+
+// ---- exchange without host round trips: the record count travels in a header record in front of the payload ----
+// counters: [0] records for the lower neighbour, [1] for the upper one, [2] slots in use, [4] error flags
+// (bit 0: a send buffer overflowed, bit 1: the slab's slot capacity overflowed on unpack).
+__global__ void k_slab_headers(uint32_t* __restrict__ counters, SlabRec* __restrict__ sendLo, SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t nl = counters[0], nh = counters[1];
+    if (nl > capLo || nh > capHi) atomicOr(&counters[4], 1u);
+    if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nl, capLo); h.flags = 0x48414c4fu; h.pad = nl; sendLo[0] = h; }
+    if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nh, capHi); h.flags = 0x48414c4fu; h.pad = nh; sendHi[0] = h; }
+}
+// recv[0] is the header (id = record count), recv[1..] the payload; appended behind slot counters[2] (+ the other
+// direction's count when `afterOther` points at that header).
+__global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __restrict__ recv, const SlabRec* __restrict__ afterOther, uint32_t recvCap,
+                                                            float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
+                                                            float* __restrict__ foam, uint32_t* __restrict__ counters, uint32_t slotCap) {
+    const uint32_t cnt = min(recv[0].id, recvCap);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cnt) return;
+    const uint32_t base = counters[2] + (afterOther ? afterOther[0].id : 0u);
+    const uint32_t d = base + i;
+    if (d >= slotCap) { atomicOr(&counters[4], 2u); return; }
+    const SlabRec r = recv[1 + i];
+    pos[d] = make_float4(r.px, r.py, r.pz, bitsf(r.flags));
+    vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
+    rp[d] = make_float2(r.rho, r.prs);
+    foam[d] = r.foam;
+}
+__global__ void k_slab_commit(uint32_t* __restrict__ counters, const SlabRec* __restrict__ recvLo, const SlabRec* __restrict__ recvHi, uint32_t slotCap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t add = (recvLo ? recvLo[0].id : 0u) + (recvHi ? recvHi[0].id : 0u);
+    counters[2] = min(counters[2] + add, slotCap);
 }
 
 __global__ void k_set_u32(uint32_t* __restrict__ p, uint32_t v) { *p = v; }

@@ -79,6 +79,8 @@ ABI_SYMBOLS = (
     "sph_device_particles", "sph_pack_render_buffer", "sph_initial_particles", "sph_download_grid", "sph_sync", "sph_kernel_times",
     "sph_debug_counters", "sph_apply_vortex_impulse", "sph_apply_attractor_impulse", "sph_set_stencil_targets",
     "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
+    "sph_slab_alloc_faces", "sph_slab_face_buffer", "sph_slab_pack_async", "sph_slab_unpack_async", "sph_slab_status",
+    "sph_comm_unique_id", "sph_comm_create", "sph_comm_destroy", "sph_slab_exchange",
 )
 # sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_list, summed over launches
 STAMP_NAMES = ("slow_waves", "slow_targets", "list_entries", "window_candidates", "lanes", "overflow_targets", "far_targets", "waves_with_fallback")
@@ -159,6 +161,15 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_slab_pack.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.sph_slab_unpack.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     L.sph_slab_download.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sph_slab_alloc_faces.argtypes = [vp, C.c_uint32]
+    L.sph_slab_face_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.sph_slab_pack_async.argtypes = [vp]
+    L.sph_slab_unpack_async.argtypes = [vp, vp, vp, C.c_uint32]
+    L.sph_slab_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.sph_comm_unique_id.argtypes = [vp]
+    L.sph_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int]
+    L.sph_comm_destroy.argtypes = [vp]
+    L.sph_slab_exchange.argtypes = [vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version", "sph_fountain_default"):

@@ -9,8 +9,10 @@ snapshot of its neighbours, so ONE exchange per substep suffices:
     pack      every rank classifies its particles by current position and emits, per z-neighbour,
               one stream of 48-byte records: migrants (now owned by the neighbour) and copies of
               its boundary-layer particles (ghosts for the neighbour)
-    exchange  counts, then payload, with at most two neighbours (torch.distributed send/recv:
-              RCCL over xGMI with backend "nccl"; "gloo" + host staging for CPU rehearsals)
+    exchange  with at most two neighbours.  Measured path: sph_slab_exchange of the C-ABI (grouped
+              ncclSend/ncclRecv = RCCL over xGMI on the engine's stream, record counts in a header record,
+              no host round trip).  Rehearsal / test paths: torch.distributed send/recv of counts then
+              payload ("gloo" + host staging on CPU boxes), or direct hand-off inside one process
     unpack    received records are appended to the local state
     dispatch  the ordinary substep; ghosts are neighbour candidates, never targets
 
@@ -34,9 +36,11 @@ assert OUT_DTYPE.itemsize == 64
 
 
 def slab_range(gz: int, rank: int, world: int):
-    """Even split of gz cell layers; every rank gets at least one layer."""
-    if world > gz:
-        raise ValueError(f"{world} ranks for {gz} cell layers")
+    """Even split of gz cell layers.  Every rank needs at least TWO layers: with a single layer a migrant that
+    arrives from below would have to be forwarded upwards as a halo copy in the same substep (it is only known after
+    this rank's own pack has run), and the upper neighbour would integrate with a neighbour missing."""
+    if world > 1 and 2 * world > gz:
+        raise ValueError(f"{world} ranks for {gz} cell layers: a z-slab needs at least 2 layers")
     return (gz * rank) // world, (gz * (rank + 1)) // world
 
 
@@ -69,6 +73,34 @@ class HipSlabEngine:
         plo = recv_lo.data_ptr() if (recv_lo is not None and n_lo) else None
         phi = recv_hi.data_ptr() if (recv_hi is not None and n_hi) else None
         _eng._check(self._L.sph_slab_unpack(self._h, plo, n_lo, phi, n_hi))
+
+    # -- exchange without host round trips (device-side counts; include/sph_abi.h) --------------------------
+    def alloc_faces(self, face_cap: int):
+        _eng._check(self._L.sph_slab_alloc_faces(self._h, int(face_cap)))
+        self.face_cap = int(face_cap)
+
+    def face_ptr(self, which: int) -> int:
+        p = C.c_void_p()
+        _eng._check(self._L.sph_slab_face_buffer(self._h, which, C.byref(p)))
+        return p.value
+
+    def pack_async(self):
+        _eng._check(self._L.sph_slab_pack_async(self._h))
+
+    def unpack_async(self, recv_lo_ptr, recv_hi_ptr, recv_cap):
+        _eng._check(self._L.sph_slab_unpack_async(self._h, recv_lo_ptr, recv_hi_ptr, int(recv_cap)))
+
+    def exchange(self, comm: "RcclComm"):
+        """pack -> grouped ncclSend/ncclRecv with the z-neighbours -> unpack, on the engine's stream (sph_slab_exchange)."""
+        _eng._check(self._L.sph_slab_exchange(self._h, comm._h))
+
+    def sync(self):
+        _eng._check(self._L.sph_sync(self._h))
+
+    def status(self):
+        out = (C.c_uint32 * 5)()
+        _eng._check(self._L.sph_slab_status(self._h, out))
+        return [int(x) for x in out]
 
     def dispatch(self, dt=-1.0):
         _eng._check(self._L.sph_set_params(self._h, C.byref(self._p)))
@@ -104,6 +136,27 @@ class HipSlabEngine:
             pass
 
 
+class RcclComm:
+    """ncclCommInitRank behind the C-ABI (sph_comm_*): one rank per process on the current HIP device.  `bcast` hands
+    rank 0's 128-byte unique id to the other ranks (a callable bytes -> bytes, e.g. a torch.distributed broadcast)."""
+
+    def __init__(self, rank: int, world: int, bcast):
+        self._L = _eng.load_library()
+        self._h = C.c_void_p()
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _eng._check(self._L.sph_comm_unique_id(buf))
+        data = bcast(bytes(buf))
+        idb = (C.c_ubyte * 128).from_buffer_copy(data)
+        _eng._check(self._L.sph_comm_create(C.byref(self._h), idb, rank, world))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self._h:
+            self._L.sph_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class HaloExchange:
     """Counts + payload exchange with the (at most two) z-neighbours over torch.distributed.
 
@@ -127,6 +180,10 @@ class HaloExchange:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            if self.transport == "direct" and str(self.device) != "cpu":
+                # req.wait() only orders torch's current stream; the engine packs / unpacks on its own stream, so the
+                # receive must have LANDED (and the sends must have left) before the engine touches the buffers again
+                self.torch.cuda.synchronize()
 
     def exchange(self, send_lo, n_lo, send_hi, n_hi, recv_lo, recv_hi):
         """Returns (m_lo, m_hi): records received from the lower / upper neighbour, written to the
@@ -200,6 +257,19 @@ class SlabSimulation:
         cap = int(len(rec) * 1.3 + 4 * face_cap)
         eng = HipSlabEngine(rec, gid.astype(np.uint32), params, z0, z1, rank > 0, rank < world - 1, cap, stream=stream)
         dev = torch.device("cuda", torch.cuda.current_device())
+        if transport == "rccl":
+            import torch.distributed as dist
+
+            def bcast(data: bytes) -> bytes:
+                t = torch.tensor(list(data), dtype=torch.uint8, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+                dist.broadcast(t, src=0, group=group)
+                return bytes(t.cpu().tolist())
+
+            eng.alloc_faces(face_cap)
+            sim = cls(eng, RcclComm(rank, world, bcast), rank, world, (z0, z1), cfg.grid, 0, lambda n: None)
+            sim.has_lo, sim.has_hi = rank > 0, rank < world - 1
+            sim._n_owned0 = len(rec)
+            return sim
         ex = HaloExchange(rank, world, group=group, transport=transport, device=dev)
         sim = cls(eng, ex, rank, world, (z0, z1), cfg.grid, face_cap,
                   lambda n: torch.zeros((n, REC_WORDS), dtype=torch.float32, device=dev))
@@ -208,6 +278,10 @@ class SlabSimulation:
 
     # -- the substep -------------------------------------------------------------------------------
     def DispatchCompute(self, overrideDt: float = -1.0):
+        if isinstance(self.exchange, RcclComm):          # the measured path: everything behind the C-ABI, no host round trip
+            self.engine.exchange(self.exchange)
+            self.engine.dispatch(overrideDt)
+            return
         n_lo, n_hi = self.engine.pack(self.send_lo, self.send_hi)
         m_lo, m_hi = self.exchange.exchange(self.send_lo, n_lo, self.send_hi, n_hi, self.recv_lo, self.recv_hi)
         self.engine.unpack(self.recv_lo, m_lo, self.recv_hi, m_hi)
@@ -257,7 +331,28 @@ class SlabGroup:
             sims.append(SlabSimulation(eng, None, r, world, (z0, z1), grid_dims, face_capacity, make_buffer))
         return cls(sims)
 
+    def enable_async(self, face_capacity: int):
+        """Exchange through the engines' own face buffers with device-side counts (sph_slab_pack_async /
+        sph_slab_unpack_async): the path sph_slab_exchange runs around its ncclSend/ncclRecv, minus the transport."""
+        for s in self.sims:
+            s.engine.alloc_faces(face_capacity)
+        self._async_cap = int(face_capacity)
+
     def DispatchCompute(self, overrideDt: float = -1.0):
+        if getattr(self, "_async_cap", 0):
+            for s in self.sims:
+                s.engine.pack_async()
+            for s in self.sims:                       # the engines run on their own streams: a pack must have finished
+                s.engine.sync()                       # before the neighbour reads it (RCCL gives that order on real ranks)
+            for r, s in enumerate(self.sims):
+                lo = self.sims[r - 1].engine.face_ptr(1) if r > 0 else None                 # lower neighbour's "send hi"
+                hi = self.sims[r + 1].engine.face_ptr(0) if r < len(self.sims) - 1 else None  # upper neighbour's "send lo"
+                s.engine.unpack_async(lo, hi, self._async_cap)
+            for s in self.sims:
+                s.engine.sync()
+            for s in self.sims:
+                s.engine.dispatch(overrideDt)
+            return
         counts = [s.engine.pack(s.send_lo, s.send_hi) for s in self.sims]
         for r, s in enumerate(self.sims):
             lo_buf, m_lo, hi_buf, m_hi = None, 0, None, 0

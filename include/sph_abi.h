@@ -235,6 +235,29 @@ int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* 
 /* Owned particles as 64-byte records (pos3, vel3, acc3, rho, P, foam, uint32 id, flags, 2 pad) into host memory. */
 int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nOut);
 
+/* ---- the same exchange without host round trips, and its RCCL transport ------------------------------------------
+ * The engine owns four device buffers of (faceCap + 1) records (send lo / hi, receive lo / hi); record 0 is a header whose
+ * `id` word carries the record count, so counts never travel through the host.  Per substep a rank calls
+ * sph_slab_exchange (pack -> one grouped ncclSend/ncclRecv per z-neighbour over xGMI -> unpack, all on the engine's
+ * stream) and then sph_dispatch.  sph_slab_pack_async / sph_slab_unpack_async are the two halves for hosts that move the
+ * buffers themselves (several slab engines in one process, another transport).  Overflows (send buffer, slot capacity)
+ * set a device-side flag that sph_slab_status / sph_slab_download report.  A `stream` of NULL at creation means an
+ * engine-owned stream: everything above is ordered on THAT stream. */
+#define SPH_COMM_ID_BYTES 128
+typedef struct SphComm SphComm;
+int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap);
+int sph_slab_face_buffer(SphEngine* e, int which /* 0 send lo, 1 send hi, 2 recv lo, 3 recv hi */, void** devPtr);
+int sph_slab_pack_async(SphEngine* e);
+int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap);
+/* Synchronises; out = {records packed for lo, for hi, slots in use, -, error flags}. */
+int sph_slab_status(SphEngine* e, uint32_t out[5]);
+/* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy: rank 0 creates the id and hands its 128 bytes to the other ranks
+ * by any means (MPI, a file, torch.distributed); one rank per process, on the current HIP device. */
+int sph_comm_unique_id(void* out128);
+int sph_comm_create(SphComm** out, const void* id128, int rank, int world);
+int sph_comm_destroy(SphComm* comm);
+int sph_slab_exchange(SphEngine* e, SphComm* comm);
+
 /* ---- measurement ----------------------------------------------------------------- */
 enum {
     SPH_K_BIN = 0,      /* cell index + histogram   (BuildGrid.comp)            */

@@ -69,6 +69,65 @@ def test_slabs_match_single_engine_and_oracle(pkg, oracle, world, neighbor):
     single.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_async_exchange_matches_single_engine(pkg, oracle, world):
+    """The exchange without host round trips (device-side counts, engine-owned face buffers: the path
+    sph_slab_exchange wraps around ncclSend/ncclRecv) gives the single-engine bits; status reports no overflow."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, world)
+    grp.enable_async(8192)
+    single = pkg.SPHFluidGPU.from_particles(P, sp)
+    want = P
+    for s in range(8):
+        if s % 3 == 0:
+            args = (1.5, 3.0, 0.1 * s, (0.2, 1.0, 0.4), -2.0, 2.0)
+            grp.ApplyWaveImpulse(*args)
+            single.ApplyWaveImpulse(*args)
+            want = oracle.wave_impulse(want, *args)
+        import torch
+        torch.cuda.synchronize()                  # the engines of the group run on their own streams
+        grp.DispatchCompute()
+        single.DispatchCompute()
+        want = oracle.substep(want, op)
+    got = halo.merge_into_records(P, grp.download())
+    assert_records_equal(got, single.download(), f"{world} slabs (async exchange) vs one engine")
+    assert_records_equal(got, want, f"{world} slabs (async exchange) vs oracle")
+    st = [s.engine.status() for s in grp.sims]
+    assert all(x[4] == 0 for x in st) and sum(x[0] + x[1] for x in st) > 0
+    single.close()
+
+
+def test_async_exchange_reports_overflow(pkg, oracle):
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, 2)
+    grp.enable_async(16)                          # far too small a face buffer
+    import torch
+    torch.cuda.synchronize()
+    grp.DispatchCompute()
+    with pytest.raises(pkg.SphError, match="overflow"):
+        grp.sims[0].engine.status()
+
+
+def test_rccl_comm_of_one_rank(pkg, oracle):
+    """RCCL itself on the one GPU of this box: a communicator of world size 1 and sph_slab_exchange on a slab without
+    neighbours (no send / recv is issued; two ranks cannot share a device).  The slab then equals the single engine."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle, n=3000, grid=14, seed=53)
+    cz, dims = _cell_z(pkg, sp, P)
+    eng = halo.HipSlabEngine(P, np.arange(len(P), dtype=np.uint32), sp, 0, dims[2], False, False, capacity=len(P) + 4096)
+    eng.alloc_faces(1024)
+    comm = halo.RcclComm(0, 1, lambda b: b)
+    for _ in range(3):
+        eng.exchange(comm)
+        eng.dispatch()
+    got = halo.merge_into_records(P, eng.download_owned())
+    assert_records_equal(got, oracle.substep(P, op, steps=3), "one-rank RCCL slab")
+    comm.close()
+    eng.close()
+
+
 def test_slabs_config2_262k(pkg):
     """BASELINE.json configs[1] size (262 144 particles, 64^3): 4 slabs == 1 engine after 5 substeps."""
     halo = importlib.import_module(PKG_NAME + ".halo")
