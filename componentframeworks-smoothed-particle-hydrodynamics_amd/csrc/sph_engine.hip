@@ -287,7 +287,8 @@ int build_grid(SphEngine* e, const SimK& k) {
     }
     if (n) {
         Timed t(e, SPH_K_SCATTER);
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n);
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n,
+                           e->slab ? e->d_slabCnt + 2 : (const uint32_t*)nullptr);
         if (sortedCopy) {
             hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
                                e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn, k.gx, k.gy);

@@ -52,8 +52,9 @@ __global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict
                                                 const uint32_t* __restrict__ slotsInUse) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool inRange = i < n;
     // z-slab mode without host round trips: n is only a launch bound, the slots that hold data are counted on the device
+    if (slotsInUse && (uint32_t)(blockIdx.x * kBlock) >= *slotsInUse) return;      // whole block beyond the data (k_scatter skips it too)
+    const bool inRange = i < n;
     const bool used = inRange && (!slotsInUse || (uint32_t)i < *slotsInUse);
     uint32_t cell = 0xFFFFFFFFu;              // also the key of dead / unused slots (z-slab mode): they get no slot
     if (used) {
@@ -159,9 +160,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cn
 // ---- counting-sort scatter: tmp[slot] = (particle id, source index) ---------------------
 __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ vel, const uint32_t* __restrict__ cellOf,
                                                     const uint32_t* __restrict__ slotOf, const uint32_t* __restrict__ cellStart,
-                                                    uint2* __restrict__ tmp, int n) {
+                                                    uint2* __restrict__ tmp, int n, const uint32_t* __restrict__ slotsInUse) {
     int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (slotsInUse && (uint32_t)i >= *slotsInUse)) return;
     if (cellOf[i] == 0xFFFFFFFFu) return;     // dead slot (z-slab mode)
     uint32_t dst = cellStart[cellOf[i]] + slotOf[i];
     tmp[dst] = make_uint2(fbits(vel[i].w), (uint32_t)i);
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
                                                       uint32_t* __restrict__ counters) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n = min(nBound, (int)counters[2]);       // counters[2] = slots that hold data (live count of the last sort)
+    if ((int)(blockIdx.x * kBlock) >= n) return;       // whole block beyond the data
     bool toLoBuf = false, toHiBuf = false;
     SlabRec r;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = r.rho = r.prs = r.foam = 0.0f; r.id = 0; r.flags = 0; r.pad = 0;

@@ -127,11 +127,13 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
     const int lane = tid & 63, wv = tid >> 6;
     // XCD-aware block mapping: blocks b and b+8 run on the same XCD (round-robin dispatch); each XCD gets one contiguous
     // eighth of the sorted order, so that its L2 holds only that part of the sorted copy.  Any mapping is correct.
-    const int nBlocks = (n + kBlock - 1) / kBlock, perXcd = (nBlocks + 7) >> 3;
+    const int bound = liveCount ? min(n, (int)*liveCount) : n;
+    // (over the LIVE slots: a z-slab launch covers the slab's slot capacity, and an eighth of the capacity per XCD would
+    // leave the last XCDs without work)
+    const int nBlocks = (bound + kBlock - 1) / kBlock, perXcd = (nBlocks + 7) >> 3;
     const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
     if (vb >= nBlocks) return;                               // whole block, uniformly
     const int sRaw = vb * kBlock + tid;
-    const int bound = liveCount ? min(n, (int)*liveCount) : n;
     bool live = sRaw < bound;                                // every lane stays to the end (the staging is a wave-wide cooperation)
     const int s = live ? sRaw : max(bound - 1, 0);
     const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];

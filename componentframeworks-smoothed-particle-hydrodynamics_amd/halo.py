@@ -252,15 +252,20 @@ class SlabSimulation:
         gx, gy, gz = cfg.grid
         z0, z1 = slab_range(gz, rank, world)
         rec, gid = _syn.make_particles(cfg, z_cells=(z0, z1))
+        # a face carries one boundary layer of copies plus the migrants; slots: owned + two ghost layers + arrivals.
+        # Kept tight on purpose: kernels are launched over the slot CAPACITY in the exchange without host round trips,
+        # and blocks launched for empty slots cost time (tools/slab_overhead_detail.py)
         per_layer = max(1, len(rec) // max(1, z1 - z0))
-        face_cap = int(per_layer * 4 + 4096)
-        cap = int(len(rec) * 1.3 + 4 * face_cap)
+        face_cap = int(per_layer * 2.5 + 4096)
+        cap = int(len(rec) * 1.06 + 2 * face_cap)
         eng = HipSlabEngine(rec, gid.astype(np.uint32), params, z0, z1, rank > 0, rank < world - 1, cap, stream=stream)
         dev = torch.device("cuda", torch.cuda.current_device())
         if transport == "rccl":
             import torch.distributed as dist
 
             def bcast(data: bytes) -> bytes:
+                if world == 1 or not dist.is_initialized():
+                    return data
                 t = torch.tensor(list(data), dtype=torch.uint8, device=dev if dist.get_backend(group) == "nccl" else "cpu")
                 dist.broadcast(t, src=0, group=group)
                 return bytes(t.cpu().tolist())

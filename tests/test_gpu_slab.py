@@ -114,7 +114,7 @@ def test_rccl_comm_of_one_rank(pkg, oracle):
     """RCCL itself on the one GPU of this box: a communicator of world size 1 and sph_slab_exchange on a slab without
     neighbours (no send / recv is issued; two ranks cannot share a device).  The slab then equals the single engine."""
     halo = importlib.import_module(PKG_NAME + ".halo")
-    P, sp, op = _scene(pkg, oracle, n=3000, grid=14, seed=53)
+    P, sp, op = _scene(pkg, oracle, n=2400, grid=14, seed=53)
     cz, dims = _cell_z(pkg, sp, P)
     eng = halo.HipSlabEngine(P, np.arange(len(P), dtype=np.uint32), sp, 0, dims[2], False, False, capacity=len(P) + 4096)
     eng.alloc_faces(1024)

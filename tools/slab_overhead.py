@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Fixed per-substep cost of the z-slab driver without any neighbour: SlabSimulation with world = 1
-(pack kernel, count read-back, Python) against the plain engine on the same particles.
+"""Fixed per-substep cost of the z-slab driver without any neighbour, against the plain engine on the same particles:
+SlabSimulation with world = 1 through (a) the host-count path (pack kernel, count read-back, Python) and (b) the C-ABI
+exchange without host round trips (sph_slab_exchange on a one-rank RCCL communicator: pack, header, unpack, commit).
 usage: slab_overhead.py [config index=3] [substeps=40]"""
 import importlib
 import json
@@ -37,5 +38,7 @@ def run(sim):
 rec, _ = syn.make_particles(cfg)
 plain = run(pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream))
 slab = run(halo.SlabSimulation.from_config(cfg, sp, 0, 1, stream=stream))
-print(json.dumps({"config": cfg.name, "substeps": steps, "plain_engine_ms": round(plain, 4), "slab_world1_ms": round(slab, 4),
-                  "fixed_slab_overhead_us": round((slab - plain) * 1e3, 1)}))
+slab_async = run(halo.SlabSimulation.from_config(cfg, sp, 0, 1, stream=stream, transport="rccl"))
+print(json.dumps({"config": cfg.name, "substeps": steps, "plain_engine_ms": round(plain, 4), "slab_world1_hostcounts_ms": round(slab, 4),
+                  "slab_world1_c_abi_exchange_ms": round(slab_async, 4), "fixed_overhead_hostcounts_us": round((slab - plain) * 1e3, 1),
+                  "fixed_overhead_c_abi_exchange_us": round((slab_async - plain) * 1e3, 1)}))
