@@ -73,6 +73,7 @@ struct SphEngine {
     // hipGraph cache of sph_dispatch_n (SPH_OPT_GRAPH): one executable graph per distinct call
     struct GraphEntry {
         uint64_t key = 0;
+        std::vector<unsigned char> material;   // full key material, compared on a hit
         hipGraphExec_t exec = nullptr;
         int postCur = 0;
         bool postAos = false, postAcc = false;
@@ -178,6 +179,9 @@ void free_particle_buffers(SphEngine* e) {
     e->cap = 0;
 }
 void free_grid_buffers(SphEngine* e) {
+    if (!e->graphs.empty() && e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);   // captured launches hold these addresses
+    e->graphs.clear();
     dev_free(e->d_cellCount); dev_free(e->d_cellStart); dev_free(e->d_blockSums);
     e->allocatedCells = 0;
 }
@@ -611,23 +615,29 @@ int sph_dispatch(SphEngine* e, float overrideDt) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     return dispatch_one(e, overrideDt);
 }
-// Key of one sph_dispatch_n call for the graph cache: everything a captured launch sequence bakes in
-// (uniforms, options, buffer addresses, host-side validity state).
-static uint64_t graph_key(const SphEngine* e, float dt, int n) {
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const void* p, size_t len) {
-        const unsigned char* b = static_cast<const unsigned char*>(p);
-        for (size_t i = 0; i < len; ++i) { h ^= b[i]; h *= 1099511628211ull; }
-    };
-    mix(&e->params, sizeof(e->params));
-    mix(&dt, sizeof(dt)); mix(&n, sizeof(n));
-    const int opts[10] = {e->optNeighbor, e->optGridBuild, e->optAos, 0, 0, 0, 0, e->cur,
-                          (e->aosValid ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0), (int)e->idBase};
-    mix(opts, sizeof(opts));
-    const void* ptrs[9] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_cellStart, e->d_cellCount, e->d_order, e->d_llNext, e->d_shapeTab, e->d_sPos};
-    mix(ptrs, sizeof(ptrs));
+// Key material of one sph_dispatch_n call for the graph cache: everything a captured launch sequence bakes in
+// (uniforms, options, every device buffer a kernel gets, host-side validity state).  A hit compares the whole material,
+// not only its hash.
+static std::vector<unsigned char> graph_material(const SphEngine* e, float dt, int n) {
+    std::vector<unsigned char> m;
+    auto add = [&](const void* p, size_t len) { const unsigned char* b = static_cast<const unsigned char*>(p); m.insert(m.end(), b, b + len); };
+    add(&e->params, sizeof(e->params));
+    add(&dt, sizeof(dt)); add(&n, sizeof(n));
+    const int opts[8] = {e->optNeighbor, e->optGridBuild, e->optAos, e->cur, (e->aosValid ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0),
+                         (int)e->idBase, e->allocatedCells, 0};
+    add(opts, sizeof(opts));
+    const void* ptrs[20] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_vel[0], e->d_vel[1], e->d_rp[0], e->d_rp[1], e->d_foam[0], e->d_foam[1], e->d_acc,
+                            e->d_cellOf, e->d_slotOf, e->d_order, e->d_tmp, e->d_cellCount, e->d_cellStart, e->d_blockSums, e->d_sPos, e->d_sVel, e->d_sOwn};
+    add(ptrs, sizeof(ptrs));
+    const void* more[3] = {e->d_llNext, e->d_shapeTab, e->d_stats};
+    add(more, sizeof(more));
     const size_t sz[2] = {e->n, e->cap};
-    mix(sz, sizeof(sz));
+    add(sz, sizeof(sz));
+    return m;
+}
+static uint64_t graph_hash(const std::vector<unsigned char>& m) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char b : m) { h ^= b; h *= 1099511628211ull; }
     return h ? h : 1;
 }
 
@@ -640,10 +650,13 @@ int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps) {
                            !e->fountain.fountainMode && !e->params.param_pause && e->n > 0;
     SphEngine::GraphEntry* hit = nullptr;
     uint64_t key = 0;
+    std::vector<unsigned char> material;
     if (graphable) {
-        key = graph_key(e, overrideDt, nSubsteps);
-        for (auto& g : e->graphs) if (g.key == key) { hit = &g; break; }
+        material = graph_material(e, overrideDt, nSubsteps);
+        key = graph_hash(material);
+        for (auto& g : e->graphs) if (g.key == key && g.material == material) { hit = &g; break; }
         if (hit && hit->exec) {
+            sph::compute_grid_extents(e->params, e->grid);       // what an eager dispatch would have refreshed (sph_grid_info, RefreshGrid)
             HIP_TRY(hipGraphLaunch(hit->exec, e->stream));
             e->cur = hit->postCur; e->aosValid = hit->postAos; e->accValid = hit->postAcc; e->internalValid = true;
             hit->lastUse = ++e->graphClock;
@@ -682,7 +695,7 @@ int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps) {
             e->graphs.erase(e->graphs.begin() + (long)v);
         }
         SphEngine::GraphEntry g;
-        g.key = key; g.lastUse = ++e->graphClock;
+        g.key = key; g.material = material; g.lastUse = ++e->graphClock;
         e->graphs.push_back(g);
     }
     return SPH_OK;

@@ -5,9 +5,11 @@
 // name, same public member names (`param_*`, `numParticles`, `particles`, `gridSizeX/Y/Z`,
 // `numCells`, `gridMinV`, `cellSize`, `box`), same method names and argument meaning
 // (`DispatchCompute`, `ResetSimulation`, `ApplyWaveImpulse`, `EffectiveHalf`,
-// `ComputeGridExtents`, `GetNumFluids`).  GL object ids (`ssbo`, `fluidVBO`, ...) have no
-// counterpart; renderers take the device pointer from DeviceParticles() instead
-// (INTEGRATION.md).  Error convention as the reference: methods return void and log
+// `ComputeGridExtents`, `GetNumFluids`, `GetFluidVBO`).  The GL object ids Scene0p touches on the
+// simulation side (`ssbo`, `GetFluidVBO()`) and the dead `riverMode` switch exist as INERT members
+// (0 / false) so that those lines compile unchanged; there is no GL buffer behind them: renderers
+// take the device pointer from DeviceParticles() or a packed buffer from PackRenderBuffer()
+// instead.  Error convention as the reference: methods return void and log
 // (Debug::FatalError only logs, Debug.cpp:54); LastError() exposes the message.
 //
 // If the host project has MATH::Vec3 / Vec4 (its "MathLibrary"), define
@@ -113,6 +115,8 @@ public:
         SetGrid(g);
     }
     size_t GetNumFluids() const { return numFluids; }                   // SPHFluid3D.cpp:601
+    // SPHFluid3D.h:37; Scene0p.cpp:85,1459,3625 only store the id.  Inert: no GL object exists (0 = "no buffer").
+    unsigned int GetFluidVBO() const { return 0u; }
 
     // ---- what replaces the GL buffer ids -------------------------------------------------
     const SPHParticle* DeviceParticles() {     // device pointer of the 80-byte array in original order (the `ssbo`)
@@ -165,6 +169,11 @@ public:
     int param_dyePattern = 0;
     float param_wallRestitution = 0.15f;
     float param_wallFriction = 0.02f;
+    // inert counterparts of members Scene0p touches (SPHFluid3D.h:72 `ssbo`: bound as binding 0 by the GL renderers,
+    // Scene0p.cpp:1625,2627,3065,3142 -- 0 binds nothing; SPHFluid3D.h:172 `riverMode`: only ever written false,
+    // Scene0p.cpp:1660 -- the river branch of DispatchCompute, SPHFluid3D.cpp:512-516, is dead code and not built)
+    unsigned int ssbo = 0;
+    bool riverMode = false;
     // fountain members, SPHFluid3D.h:161-168 (step 6 of DispatchCompute, :519)
     bool fountainMode = false;
     MATH::Vec3 fountainOffset = MATH::Vec3(0.0f, -5.0f, 0.0f);

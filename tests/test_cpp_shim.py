@@ -29,7 +29,7 @@ def test_shim_compiles_and_links_against_the_c_abi(pkg):
                  "param_h", "param_mass", "param_restDensity", "param_gasConstant", "param_viscosity", "param_gravityY",
                  "param_surfaceTension", "param_timeStep", "param_pause", "param_boxCenter", "param_boxHalf", "param_boxEulerDeg",
                  "param_shapeType", "param_shapeAux", "param_wallRestitution", "param_wallFriction", "numParticles", "particles",
-                 "gridSizeX", "numCells", "gridMinV", "cellSize"):
+                 "gridSizeX", "numCells", "gridMinV", "cellSize", "GetFluidVBO", "ssbo", "riverMode"):
         assert name in src, name
 
 

@@ -411,29 +411,53 @@ def test_unreasonable_members_are_refused_not_faulted(pkg):
 
 
 @pytest.mark.parametrize("aos", [0, 1])
-def test_pack_render_buffer(pkg, aos):
-    """sph_pack_render_buffer: the packed float4 a renderer would consume equals the 80-byte records."""
+def test_pack_render_buffer(pkg, oracle, aos):
+    """sph_pack_render_buffer against the ORACLE's output records (not the engine's own download): what the reference's
+    renderers read from binding 0 (fluidDepth.vert / particleImpostor.vert: pos, density, padA foam, |vel|, padB dye),
+    one float4 per particle in original order; ghosts keep their slot."""
     import torch
     rec, sp = small_scene(pkg, n=2500, grid=14, seed=44)
-    rec["padB"] = np.linspace(0, 1, len(rec), dtype=np.float32)
+    rec["padB"] = np.linspace(0, 1, len(rec), dtype=np.float32)            # dye: an INPUT field the substep never writes
+    rec["isGhost"][100:110] = 1
+    rec["isActive"][100:105] = 1
     f = make_engine(pkg, rec, sp)
     f.set_option(pkg.SPH_OPT_AOS_MODE, aos)
     f.DispatchN(4)
+    want = oracle.substep(rec, to_oracle_params(oracle, sp), steps=4)
     out = torch.zeros((len(rec), 4), dtype=torch.float32, device="cuda")
-    want = None
     for mode in range(5):
         f.pack_render_buffer(out.data_ptr(), mode)
         f.sync()
         got = out.cpu().numpy()
-        if want is None:
-            want = f.download()
-        w = {0: np.ones(len(rec), np.float32), 1: want["density"], 2: want["padA"], 4: want["padB"]}.get(mode)
-        assert np.array_equal(got[:, :3], want["pos"][:, :3])
+        assert np.array_equal(got[:, :3], want["pos"][:, :3]), mode
         if mode == 3:
-            v = want["vel"][:, :3].astype(np.float64)
-            np.testing.assert_allclose(got[:, 3], np.sqrt((v * v).sum(1)), rtol=1e-6)
+            v = want["vel"][:, :3]
+            speed = np.sqrt(((v[:, 2] * v[:, 2]).astype(np.float64) + ((v[:, 1] * v[:, 1]).astype(np.float64) + (v[:, 0] * v[:, 0]).astype(np.float32))).astype(np.float32))
+            np.testing.assert_allclose(got[:, 3], speed, rtol=2e-7)
         else:
-            assert np.array_equal(got[:, 3], w)
+            w = {0: np.ones(len(rec), np.float32), 1: want["density"], 2: want["padA"], 4: rec["padB"]}[mode]
+            assert np.array_equal(got[:, 3], w), mode
     with pytest.raises(pkg.SphError, match="size mismatch"):
         pkg.engine._check(f._L.sph_pack_render_buffer(f._h, out.data_ptr(), len(rec) - 1, 0))
+    f.close()
+
+
+def test_pack_render_buffer_known_answer(pkg):
+    """Hand-computed: three uploaded records, no substep -- the pack must pick pos @0, density @48, padA @56, padB @60 and
+    |vel| of vel @16 of the 80-byte record (SPHFluid3D.h:12-24)."""
+    import torch
+    _, sp = small_scene(pkg, n=300, grid=10, seed=38)
+    rec = np.zeros(3, pkg.PARTICLE_DTYPE)
+    rec["pos"][:, :3] = [[1, 2, 3], [-1, 0.5, 0.25], [0, 0, 0]]
+    rec["pos"][:, 3] = 9.0                                                  # pos.w is not part of the pack
+    rec["vel"][:, :3] = [[3, 4, 0], [0, 0, 2], [1, 2, 2]]
+    rec["density"], rec["pressure"], rec["padA"], rec["padB"] = [10, 20, 30], [7, 7, 7], [0.5, 0.25, 0.125], [0.1, 0.2, 0.3]
+    f = make_engine(pkg, rec, sp)
+    out = torch.zeros((3, 4), dtype=torch.float32, device="cuda")
+    expect = {0: [1, 1, 1], 1: [10, 20, 30], 2: [0.5, 0.25, 0.125], 3: [5, 2, 3], 4: np.float32([0.1, 0.2, 0.3])}
+    for mode, w in expect.items():
+        f.pack_render_buffer(out.data_ptr(), mode)
+        f.sync()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, :3], rec["pos"][:, :3]) and np.array_equal(got[:, 3], np.float32(w)), (mode, got)
     f.close()

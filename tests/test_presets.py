@@ -97,3 +97,43 @@ def test_shipped_presets_match_oracle(pkg, oracle, presets, name):
     f.DispatchN(12)
     assert_records_equal(f.download(), oracle.substep(rec, op, steps=12, fountain=of), name)
     f.close()
+
+
+# ---- pinned by the reference itself: oracle/_ref = the reference's PresetIO.cpp (tests/golden/make_presets_parsed.py) ----
+PARSED = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "presets_parsed.json")))
+_F_SENT, _I_SENT, _V_SENT = -12345.5, -777, [-1.25, -2.5, -3.75]
+
+
+def _fbits(x):
+    return format(int(np.float32(x).view(np.uint32)), "08x")
+
+
+def _same_float(hexbits, got):
+    want = np.uint32(int(hexbits, 16)).view(np.float32)
+    return (np.isnan(want) and np.isnan(np.float32(got))) or _fbits(got) == hexbits
+
+
+@pytest.mark.parametrize("name", sorted(PARSED["presets"]) + ["__" + k for k in sorted(PARSED["edge"])])
+def test_loader_equals_the_references_presetio(presets, name):
+    """presets.parse / get_f / get_i / get_b / get_f3 against what PresetIO::Parse / GetF / GetI / GetB / GetF3 of the
+    reference (compiled as oracle/_ref) returned for the same text: the 13 shipped presets and the edge-case files."""
+    if name.startswith("__"):
+        ref = PARSED["edge"][name[2:]]
+        kv = presets.parse(PARSED["edge_text"][name[2:]])
+    else:
+        ref = PARSED["presets"][name]
+        kv_all = presets.parse("".join(f"{k}={v}\n" for k, v in ref["kv"].items()))     # the file's own pairs, re-parsed
+        assert kv_all == ref["kv"]
+        kv = kv_all
+        # the committed extraction of the shipped preset (presets.json) is a subset of what the reference parsed
+        assert all(ref["kv"].get(k) == v for k, v in PRESETS[name].items())
+    assert ref["loaded"] and kv == ref["kv"]
+    for key, hexbits in ref["f"].items():
+        assert _same_float(hexbits, presets.get_f(kv, key, _F_SENT)), (key, kv.get(key))
+    for key, want in ref["i"].items():
+        assert presets.get_i(kv, key, _I_SENT) == want, (key, kv.get(key))
+    for key, (w0, w1) in ref["b"].items():
+        assert presets.get_b(kv, key, False) == bool(w0) and presets.get_b(kv, key, True) == bool(w1), key
+    for key, want in ref["v"].items():
+        got = presets.get_f3(kv, key, _V_SENT)
+        assert [_fbits(x) for x in got] == want, (key, kv.get(key), got)
