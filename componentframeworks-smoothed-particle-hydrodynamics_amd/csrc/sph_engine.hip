@@ -390,7 +390,7 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
         Timed t(e, SPH_K_SPH);
         if (e->optNeighbor == 2) {
-            hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n) + 7) / 8)), dim3(kBlock), 0, e->stream, k, S, in, out,
+            hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n, SPH_LIST_BLOCK) + 7) / 8)), dim3(SPH_LIST_BLOCK), 0, e->stream, k, S, in, out,
                                e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
         } else {
             hipLaunchKernelGGL(k_sph_slow, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, n);

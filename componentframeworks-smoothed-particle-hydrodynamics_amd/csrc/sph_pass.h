@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 #ifndef SPH_LIST_WAVES
 #define SPH_LIST_WAVES 5     // __launch_bounds__ minimum waves per SIMD (5: at most 96 VGPRs, 20 waves per CU with 32 KB of LDS per block)
 #endif
+#ifndef SPH_LIST_BLOCK
+#define SPH_LIST_BLOCK 256   // threads per block of k_sph_list
+#endif
 #ifndef SPH_LIST_EPS
 #define SPH_LIST_EPS 0.06f  // slack of the list around the predicted position, in units of h
 #endif
@@ -117,12 +120,13 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 // stages their union in a wave-private LDS window with coalesced loads.  Sweeps 2 / 3 touch only the listed
 // neighbours.  Lists and windows are private to the thread / the wave: no __syncthreads.
 template <int MAXN, int UNROLL, int CAP>
-__global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n, int dbg,
                                                      unsigned long long* __restrict__ stats) {
-    __shared__ uint16_t nl[MAXN + UNROLL][kBlock];   // entry e of thread t: (row << 12) | (slot - rowA[row]); rows >= MAXN absorb the writes of a full list
-    __shared__ uint32_t rowA[kBlock / 64][12];       // per wave: first slot of the wave's union of each of the 9 candidate rows
-    __shared__ float4 stage[kBlock / 64][CAP];
+    constexpr int kB = SPH_LIST_BLOCK;       // wave-private LDS only: the block size is just a dispatch / LDS granule
+    __shared__ uint16_t nl[MAXN + UNROLL][kB];   // entry e of thread t: (row << 12) | (slot - rowA[row]); rows >= MAXN absorb the writes of a full list
+    __shared__ uint32_t rowA[kB / 64][12];       // per wave: first slot of the wave's union of each of the 9 candidate rows
+    __shared__ float4 stage[kB / 64][CAP];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     // XCD-aware block mapping: blocks b and b+8 run on the same XCD (round-robin dispatch); each XCD gets one contiguous
@@ -130,10 +134,10 @@ __global__ __launch_bounds__(kBlock, SPH_LIST_WAVES) void k_sph_list(SimK k, Sor
     const int bound = liveCount ? min(n, (int)*liveCount) : n;
     // (over the LIVE slots: a z-slab launch covers the slab's slot capacity, and an eighth of the capacity per XCD would
     // leave the last XCDs without work)
-    const int nBlocks = (bound + kBlock - 1) / kBlock, perXcd = (nBlocks + 7) >> 3;
+    const int nBlocks = (bound + kB - 1) / kB, perXcd = (nBlocks + 7) >> 3;
     const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
     if (vb >= nBlocks) return;                               // whole block, uniformly
-    const int sRaw = vb * kBlock + tid;
+    const int sRaw = vb * kB + tid;
     bool live = sRaw < bound;                                // every lane stays to the end (the staging is a wave-wide cooperation)
     const int s = live ? sRaw : max(bound - 1, 0);
     const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];

@@ -284,6 +284,35 @@ def test_all_particles_in_one_cell(pkg, oracle):
         f.close()
 
 
+@pytest.mark.parametrize("neighbor", [2, 1])
+def test_download_grid_before_first_dispatch(pkg, oracle, neighbor):
+    """sph_download_grid enters the grid build (k_rank writes the sorted copy) BEFORE any dispatch, again after an upload
+    and after ResetSimulation re-allocated every buffer: the sorted copy must exist on each of these entries (the round-1
+    abort of 07:14, DESIGN.md section 11: a work-in-progress build allocated it in the dispatch path only)."""
+    rec, sp = small_scene(pkg, n=2500, grid=14, seed=45)
+    op = to_oracle_params(oracle, sp)
+    f = make_engine(pkg, rec, sp, neighbor)
+    b = oracle.build_grid(rec, op)
+    cnt, pcell = f.download_grid()                           # first GPU work of this engine
+    assert np.array_equal(pcell, b["particle_cell"]) and np.array_equal(cnt, np.diff(b["cell_start"]))
+    rec2 = rec.copy()
+    rec2["pos"][:, 0] *= np.float32(0.5)
+    f.upload(rec2)
+    cnt, pcell = f.download_grid()                           # right after an upload
+    assert np.array_equal(pcell, oracle.build_grid(rec2, op)["particle_cell"])
+    f.DispatchCompute()
+    assert_records_equal(f.download(), oracle.substep(rec2, op), "substep after download_grid")
+    g = pkg.SPHFluidGPU(5000, seed=3)
+    g.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)
+    g.numParticles = 9000
+    g.ResetSimulation(seed=4)                                # frees and re-creates every particle buffer
+    cnt, _ = g.download_grid()
+    assert cnt.sum() == g.GetNumFluids()
+    g.DispatchCompute()
+    f.close()
+    g.close()
+
+
 def test_full_size_properties_config3(pkg):
     """4M particles / 128^3 (BASELINE.json configs[2]) is too big for the oracle in a test, so
     check size-independent properties: k_sph_list == k_sph_slow bit for bit, velocity cap, containment."""
