@@ -278,12 +278,19 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
                 for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
                 continue;
             }
-            for (uint32_t q = a; q < b; ++q) {
-                const float4 J = S.posI[q];
-                const float dx = cpx - J.x, dy = cpy - J.y, dz = cpz - J.z;
-                nl[c][tid] = (uint16_t)((r << 12) | (int)(q - base));
-                c += dot3(dx, dy, dz, dx, dy, dz) < k.h2 ? 1 : 0;
-                if (__any(c >= MAXN)) { listed(c, f); c = 0; }
+            constexpr int G = 4;                               // candidates per step: G loads in flight, one fullness test
+            static_assert(UNROLL + MAXN - G >= 8, "chunk rows");
+            for (uint32_t q = a; q < b; q += G) {
+                float4 J[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) J[u] = S.posI[min(q + (uint32_t)u, b - 1u)];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const float dx = cpx - J[u].x, dy = cpy - J[u].y, dz = cpz - J[u].z;
+                    nl[c][tid] = (uint16_t)((r << 12) | (int)(q + (uint32_t)u - base));
+                    c += (q + (uint32_t)u < b && dot3(dx, dy, dz, dx, dy, dz) < k.h2) ? 1 : 0;
+                }
+                if (__any(c > MAXN + UNROLL - 1 - G)) { listed(c, f); c = 0; }   // the next step may add G more rows
             }
         }
         listed(c, f);
