@@ -15,8 +15,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rec, _ = syn.make_particles(cfg)
 sp = pkg.default_params(**syn.params_fields(cfg))
 out = {"config": cfg.name, "steps": steps}
-for label, build, neighbor in (("counting_sort+sorted_gather", 0, 2), ("counting_sort+lds_tile", 0, 0), ("counting_sort+gather", 0, 1),
-                               ("linked_list", 1, 0)):
+for label, build, neighbor in (("counting_sort+k_sph_list", 0, 2), ("counting_sort+k_sph_slow", 0, 1), ("linked_list", 1, 2)):
     sim = pkg.SPHFluidGPU.from_particles(rec, sp)
     sim.set_option(pkg.SPH_OPT_GRID_BUILD, build)
     sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)

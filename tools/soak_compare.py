@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Long-run cross-check at sizes the CPU oracle cannot follow: the three SPH passes advance the same
-scene for many substeps and must stay bit-identical (every fallback path gets exercised as the fluid
-column collapses: list overflow, window overflow, sweep-3 re-scan, tiled sub-boxes and slow queue).
-usage: soak_compare.py [config index=2] [substeps=600] [check every=100] [passes=2,1,0]"""
+"""Long-run cross-check at sizes the CPU oracle cannot follow: the two SPH passes (2 = k_sph_list, 1 = k_sph_slow) advance
+the same scene for many substeps and must stay bit-identical (every fallback path gets exercised as the fluid column
+collapses: window overflow, list overflow -> chunked sweeps, sweep-3 slack).
+usage: soak_compare.py [config index=2] [substeps=600] [check every=100] [passes=2,1]"""
 import importlib
 import os
 import sys
@@ -16,7 +16,7 @@ syn = pkg.synthetic
 ci = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-kinds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2,1,0").split(",")]
+kinds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2,1").split(",")]
 cfg = syn.CONFIGS[ci]
 sp = pkg.default_params(**syn.params_fields(cfg))
 rec, _ = syn.make_particles(cfg)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SPH-pass time of each neighbour kernel on a bench workload near its initial state.
-usage: time_kernels.py [config index=3] [neighbor ids, e.g. 0,2] [substeps=30] [untimed substeps first=5]"""
+usage: time_kernels.py [config index=3] [neighbor ids, e.g. 2,1] [substeps=30] [untimed substeps first=5]"""
 import importlib
 import json
 import os
