@@ -109,15 +109,26 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sm, ui
     return base + inc - v;
 }
 
+// Each thread owns kScanItems CONSECUTIVE cells (four 16-byte loads), so a 4096-cell tile needs one block-wide scan.
+__device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, int c0, int numCells, uint32_t (&v)[kScanItems]) {
+    if (c0 + kScanItems <= numCells) {
+        const uint4* p = reinterpret_cast<const uint4*>(cnt + c0);
+#pragma unroll
+        for (int j = 0; j < kScanItems / 4; ++j) { const uint4 q = p[j]; v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) v[j] = (c0 + j < numCells) ? cnt[c0 + j] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ blockSums, int numCells) {
     __shared__ uint32_t sm[4];
-    const int base = blockIdx.x * kScanTile;
+    const int c0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    scan_load16(cnt, c0, numCells, v);
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        int c = base + j * kBlock + threadIdx.x;
-        if (c < numCells) s += cnt[c];
-    }
+    for (int j = 0; j < kScanItems; ++j) s += v[j];
     uint32_t total;
     (void)block_excl_scan(s, sm, total);
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
@@ -141,20 +152,29 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict_
 __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ blockSums,
                                                        uint32_t* __restrict__ cellStart, int numCells, uint32_t nTotal) {
     __shared__ uint32_t sm[4];
-    const int base = blockIdx.x * kScanTile;
-    uint32_t carry = blockSums[blockIdx.x];
-#pragma unroll 1
-    for (int j = 0; j < kScanItems; ++j) {
-        int c = base + j * kBlock + threadIdx.x;
-        uint32_t v = (c < numCells) ? cnt[c] : 0u;
-        uint32_t total;
-        uint32_t ex = block_excl_scan(v, sm, total);
-        if (c < numCells) { cellStart[c] = carry + ex; cnt[c] = 0u; }
-        carry += total;
+    const int c0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    scan_load16(cnt, c0, numCells, v);
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) { const uint32_t t = v[j]; v[j] = s; s += t; }       // exclusive prefix inside the thread
+    uint32_t total;
+    const uint32_t off = blockSums[blockIdx.x] + block_excl_scan(s, sm, total);
+    if (c0 + kScanItems <= numCells) {
+        uint4* ps = reinterpret_cast<uint4*>(cellStart + c0);
+        uint4* pc = reinterpret_cast<uint4*>(cnt + c0);
+#pragma unroll
+        for (int j = 0; j < kScanItems / 4; ++j) {
+            ps[j] = make_uint4(off + v[4 * j], off + v[4 * j + 1], off + v[4 * j + 2], off + v[4 * j + 3]);
+            pc[j] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) if (c0 + j < numCells) { cellStart[c0 + j] = off + v[j]; cnt[c0 + j] = 0u; }
     }
     // total = live particles (in z-slab mode nTotal, the slot count, also covers dead slots)
     (void)nTotal;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) cellStart[numCells] = carry;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) cellStart[numCells] = blockSums[blockIdx.x] + total;
 }
 
 // ---- counting-sort scatter: tmp[slot] = (particle id, source index) ---------------------

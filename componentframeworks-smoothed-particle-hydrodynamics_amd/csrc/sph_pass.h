@@ -297,9 +297,17 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
     };
     auto force_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
     auto xsph_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
+#if defined(SPH_LIST_CUT) && SPH_LIST_CUT == 1   // timing experiment only (tools/ab_variants.sh): stop after sweep 1
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cnt, o.ay, o.az, o.rho, o.prs, O.y);
+    return;
+#endif
     // ---- sweep 2 ----
     if (listOk) listed(cnt, force_at); else chunked(o.px, o.py, o.pz, force_at);
     integrate(k, o);
+#if defined(SPH_LIST_CUT) && SPH_LIST_CUT == 2   // timing experiment only: stop after sweep 2
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, O.y);
+    return;
+#endif
     // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
     const float mx = o.px - qx, my = o.py - qy, mz = o.pz - qz;
     const float lim = 0.98f * eps;
