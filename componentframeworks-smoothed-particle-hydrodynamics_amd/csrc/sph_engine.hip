@@ -108,6 +108,10 @@ struct SphEngine {
     sph::SlabRec* d_face[4] = {nullptr, nullptr, nullptr, nullptr};   // engine-owned halo buffers: send lo / hi, recv lo / hi ((faceCap + 1) records, record 0 = header)
     uint32_t faceCap = 0;
     SphFountain fountain{};                 // fountain* members (SPHFluid3D.h:161-168)
+    SphRiver river{};                       // river / terrain members (SPHFluid3D.h:171-196)
+    std::vector<float> terrainHeights;      // CPU copy of the heightfield (:175); empty = river step off (:512)
+    float* d_terrain = nullptr;             // terrainSSBO (binding 7 of TerrainConstraints.comp)
+    size_t terrainCap = 0;
     float4 *d_sPos = nullptr, *d_sVel = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state (gather2 pass)
     size_t sortedCap = 0;
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
@@ -402,7 +406,23 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         const uint32_t* live = (e->slab && e->optGridBuild != 1) ? e->d_cellStart + k.numCells : nullptr;
         hipLaunchKernelGGL(k_obb_ext, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->shapeTab, out.pos, out.vel, live, n);
     }
-    if (e->fountain.fountainMode) {                                         // :519, :526-544
+    const bool riverOn = e->river.riverMode && !e->terrainHeights.empty();   // :512
+    if (riverOn) {                                                           // :511-516, DispatchTerrainConstraints / ChannelConstraint / StreamEmit
+        if (e->slab) return fail(SPH_ERR_STATE, "riverMode on a z-slab engine: recycled particles jump across slabs (single-GPU engines only)");
+        if (n) {
+            const SphParams& p = e->params;
+            const SphRiver& r = e->river;
+            RiverK rk{r.terrainW, r.terrainH, r.terrainWorldMinX, r.terrainWorldMinZ, r.terrainWorldSizeX, r.terrainWorldSizeZ,
+                      0.02f, 1.0f - 0.05f, p.param_boxCenter[0], r.riverAmp, r.riverFreq, r.riverPhase, r.riverChannelWidth,
+                      80.0f, p.param_timeStep, r.riverSinkY, r.riverSinkZMax, r.riverEmitterPos[0], r.riverEmitterPos[1], r.riverEmitterPos[2],
+                      r.riverEmitterVel[0], r.riverEmitterVel[1], r.riverEmitterVel[2], r.riverEmitterRadius,
+                      r.riverSinkZMax - r.riverEmitterPos[2], p.param_restDensity};
+            Timed t(e, SPH_K_OTHER);
+            hipLaunchKernelGGL(k_river, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, rk, e->d_terrain, out.pos, out.vel, out.rp,
+                               fuseAos ? (float4*)nullptr : e->d_acc, fuseAos ? e->d_aos : (SphParticle*)nullptr, e->d_aos, e->idBase, n);
+        }
+    }
+    if (e->fountain.fountainMode && !e->river.riverMode) {                  // :519, :526-544
         if (e->slab) return fail(SPH_ERR_STATE, "fountainMode on a z-slab engine: recycled particles jump across slabs (single-GPU engines only)");
         if (n) {
             float half[3];
@@ -498,6 +518,7 @@ static int create_common(SphEngine** out, const SphParams* params, void* stream,
     if (ndev <= 0) return fail(SPH_ERR_HIP, "no HIP device: this engine has no CPU fallback");
     SphEngine* e = new SphEngine();
     sph_fountain_default(&e->fountain);
+    sph_river_default(&e->river);
     e->params = *params;
     if (stream) { e->stream = (hipStream_t)stream; e->ownStream = false; }
     else {
@@ -541,6 +562,7 @@ int sph_destroy(SphEngine* e) {
     free_grid_buffers(e);
     dev_free(e->d_dbg);
     dev_free(e->d_stencil);
+    dev_free(e->d_terrain);
     dev_free(e->d_stats);
     for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -556,7 +578,10 @@ int sph_reset(SphEngine* e, size_t nRequested, uint32_t seed) {       // SPHFlui
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<SphParticle> v;
     float m;
-    sph::spawn_particles(e->params, nRequested, seed, v, m);
+    if (e->river.riverMode && !e->terrainHeights.empty())             // :104
+        sph::spawn_river_particles(e->params, e->river, e->terrainHeights.data(), nRequested, seed, v, m);
+    else
+        sph::spawn_particles(e->params, nRequested, seed, v, m);
     e->params.param_mass = m;
     sph::compute_grid_extents(e->params, e->grid);
     free_particle_buffers(e);                                         // :714-719 delete + recreate
@@ -647,7 +672,7 @@ int sph_dispatch_n(SphEngine* e, float overrideDt, int nSubsteps) {
     // at the default 50 000 particles that loop is launch-bound, so the second identical call is
     // captured into a hipGraph and replayed from then on.
     const bool graphable = e->optGraph && nSubsteps >= 2 && !e->slab && !e->optTiming && !e->debugFlags &&
-                           !e->fountain.fountainMode && !e->params.param_pause && e->n > 0;
+                           !e->fountain.fountainMode && !e->river.riverMode && !e->params.param_pause && e->n > 0;
     SphEngine::GraphEntry* hit = nullptr;
     uint64_t key = 0;
     std::vector<unsigned char> material;
@@ -792,6 +817,61 @@ int sph_set_fountain(SphEngine* e, const SphFountain* f) {
 int sph_get_fountain(const SphEngine* e, SphFountain* out) {
     if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
     *out = e->fountain;
+    return SPH_OK;
+}
+
+void sph_river_default(SphRiver* out) {                     // SPHFluid3D.h:171-196
+    if (out) sph::river_default(*out);
+}
+static int validate_river(const SphRiver& r) {
+    if (r.terrainW < 2 || r.terrainH < 2 || r.terrainW > 4096 || r.terrainH > 4096) return fail(SPH_ERR_ARG, "terrainW / terrainH %d x %d: 2..4096 each", r.terrainW, r.terrainH);
+    return SPH_OK;
+}
+int sph_generate_river_terrain(SphParams* params, int seed, SphRiver* river, float* heights) {
+    if (!params || !river || !heights) return fail(SPH_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = validate_river(*river))) return rc;
+    sph::river_terrain(*params, seed, *river, heights);
+    return SPH_OK;
+}
+int sph_spawn_river_particles(const SphParams* params, const SphRiver* river, const float* heights, size_t nRequested, uint32_t seed,
+                              SphParticle* out, size_t* nOut, float* massOut) {
+    if (!params || !river || !heights || !out || !nOut || !massOut) return fail(SPH_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = validate_river(*river))) return rc;
+    std::vector<SphParticle> v;
+    float m;
+    sph::spawn_river_particles(*params, *river, heights, nRequested, seed, v, m);
+    std::memcpy(out, v.data(), v.size() * sizeof(SphParticle));
+    *nOut = v.size();
+    *massOut = m;
+    return SPH_OK;
+}
+int sph_set_river(SphEngine* e, const SphRiver* river, const float* heights) {
+    if (!e || !river) return fail(SPH_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = validate_river(*river))) return rc;
+    const size_t cells = (size_t)river->terrainW * (size_t)river->terrainH;
+    if (heights) {                                                   // :868-873
+        for (size_t i = 0; i < cells; ++i) if (!std::isfinite(heights[i])) return fail(SPH_ERR_ARG, "terrain height %zu is not finite", i);
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (cells > e->terrainCap) {
+            dev_free(e->d_terrain);
+            e->terrainCap = 0;
+            if ((rc = dev_alloc(&e->d_terrain, cells))) return rc;
+            e->terrainCap = cells;
+        }
+        e->terrainHeights.assign(heights, heights + cells);
+        HIP_TRY(hipMemcpy(e->d_terrain, heights, cells * sizeof(float), hipMemcpyHostToDevice));
+    } else if (!e->terrainHeights.empty() && e->terrainHeights.size() != cells) {
+        return fail(SPH_ERR_ARG, "terrainW x terrainH changed to %d x %d without a new heightfield", river->terrainW, river->terrainH);
+    }
+    e->river = *river;
+    return SPH_OK;
+}
+int sph_get_river(const SphEngine* e, SphRiver* out) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    *out = e->river;
     return SPH_OK;
 }
 

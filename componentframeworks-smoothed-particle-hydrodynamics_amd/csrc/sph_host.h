@@ -295,4 +295,126 @@ inline void spawn_particles(const SphParams& p, size_t nRequested, uint32_t seed
             }
 }
 
+// ---- river / stream mode, host side (SPHFluid3D.h:171-206) ---------------------------------------------------------
+inline void river_default(SphRiver& r) {                                       // SPHFluid3D.h:172-196
+    r = SphRiver{0, 64, 64, -7.0f, -10.0f, 14.0f, 20.0f, {0.0f, 3.0f, -9.0f}, {0.0f, -0.5f, 4.0f}, 1.5f, -8.5f, 9.0f,
+                 2.0f, 0.25f, 0.0f, 3.0f, 3.5f, 0.3f};
+}
+
+// std::srand / std::rand of the Microsoft C runtime (the reference is built with Visual Studio): RAND_MAX = 0x7fff.
+struct MsvcRand {
+    uint32_t hold;
+    explicit MsvcRand(unsigned seed) : hold(seed) {}
+    int next() { hold = hold * 214013u + 2531011u; return int((hold >> 16) & 0x7fffu); }
+    float frand() { return float(next()) / 32767.0f; }                        // std::rand() / float(RAND_MAX), :774
+};
+
+// GenerateRiverTerrain, SPHFluid3D.cpp:772-878 (without the GL upload).
+inline void river_terrain(SphParams& p, int seed, SphRiver& r, float* heights) {
+    MsvcRand rnd(static_cast<unsigned>(seed));
+    r.riverAmp = 0.5f + rnd.frand() * 1.5f;                                    // :777-782
+    r.riverFreq = 0.18f + rnd.frand() * 0.18f;
+    r.riverPhase = rnd.frand() * 6.2831f;
+    r.riverChannelWidth = 1.8f + rnd.frand() * 1.2f;
+    r.riverChannelDepth = 3.5f + rnd.frand() * 1.0f;
+    r.riverSlopeDrop = 0.3f + rnd.frand() * 0.5f;
+    float ph[8];
+    for (float& x : ph) x = rnd.frand() * 6.2831f;
+    r.terrainWorldMinX = p.param_boxCenter[0] - p.param_boxHalf[0];            // :792-795
+    r.terrainWorldMinZ = p.param_boxCenter[2] - p.param_boxHalf[2];
+    r.terrainWorldSizeX = 2.0f * p.param_boxHalf[0];
+    r.terrainWorldSizeZ = 2.0f * p.param_boxHalf[2];
+    const float yBase = p.param_boxCenter[1] - p.param_boxHalf[1];
+    const float depth = r.riverChannelDepth, drop = r.riverSlopeDrop;
+    auto centerline = [&](float wz) { return p.param_boxCenter[0] + r.riverAmp * std::sin(r.riverFreq * wz + r.riverPhase); };
+    for (int iz = 0; iz < r.terrainH; ++iz) {
+        const float wz = r.terrainWorldMinZ + (float(iz) / float(r.terrainH - 1)) * r.terrainWorldSizeZ;
+        const float tFlow = (wz - r.terrainWorldMinZ) / r.terrainWorldSizeZ;
+        const float riverFloor = yBase + 1.0f - tFlow * drop;                  // :818
+        const float channelEdge = riverFloor + depth;
+        const float cX = centerline(wz);
+        for (int ix = 0; ix < r.terrainW; ++ix) {
+            const float wx = r.terrainWorldMinX + (float(ix) / float(r.terrainW - 1)) * r.terrainWorldSizeX;
+            const float dist = std::fabs(wx - cX);
+            float h = channelEdge + 3.0f;                                      // plateau :824
+            h += 0.5f * std::sin(wx * 0.35f + ph[0]) * std::cos(wz * 0.28f + ph[1]);
+            h += 0.25f * std::sin(wx * 0.70f + ph[2]) * std::sin(wz * 0.60f + ph[3]);
+            h += 0.12f * std::sin(wx * 1.40f + ph[4]) * std::cos(wz * 1.20f + ph[5]);
+            if (dist < r.riverChannelWidth) {                                  // trapezoidal channel :830-840
+                const float u = dist / r.riverChannelWidth;
+                const float floorFrac = 0.50f;
+                if (u < floorFrac) h = riverFloor;
+                else {
+                    const float uw = (u - floorFrac) / (1.0f - floorFrac);
+                    h = riverFloor + depth * uw * uw;
+                }
+            } else {
+                h = std::fmax(h, channelEdge + 0.3f);
+            }
+            heights[iz * r.terrainW + ix] = std::fmax(h, yBase - 0.3f);         // :847
+        }
+    }
+    const float emitterZ = r.terrainWorldMinZ + 0.5f;                          // :853-861
+    r.riverEmitterPos[0] = centerline(emitterZ);
+    r.riverEmitterPos[1] = (yBase + 1.0f) + depth * 0.5f;
+    r.riverEmitterPos[2] = emitterZ;
+    r.riverEmitterVel[0] = 0.0f; r.riverEmitterVel[1] = -0.5f; r.riverEmitterVel[2] = 0.5f;
+    r.riverEmitterRadius = r.riverChannelWidth * 0.35f;
+    r.riverSinkY = yBase + 0.3f;
+    r.riverSinkZMax = p.param_boxCenter[2] + p.param_boxHalf[2] - 0.5f;
+    p.param_gravityY = -120.0f;                                                // :864-865
+    p.param_gravityZ = 0.0f;
+}
+
+// The sampleH lambda of the spawn (SPHFluid3D.cpp:113-126): four-product bilinear form.
+inline float river_sample_host(const SphRiver& r, const float* T, float wx, float wz) {
+    float u = (wx - r.terrainWorldMinX) / r.terrainWorldSizeX * float(r.terrainW - 1);
+    float v = (wz - r.terrainWorldMinZ) / r.terrainWorldSizeZ * float(r.terrainH - 1);
+    u = std::fmax(0.0f, std::fmin(float(r.terrainW - 2), u));
+    v = std::fmax(0.0f, std::fmin(float(r.terrainH - 2), v));
+    const int ix = int(u), iz = int(v);
+    const float fx = u - float(ix), fz = v - float(iz);
+    const float* row0 = T + iz * r.terrainW + ix;
+    const float* row1 = row0 + r.terrainW;
+    return row0[0] * (1 - fx) * (1 - fz) + row0[1] * fx * (1 - fz) + row1[0] * (1 - fx) * fz + row1[1] * fx * fz;
+}
+
+// InitializeParticles, river branch (SPHFluid3D.cpp:104-160): channel fill, then the rest at the emitter.
+inline void spawn_river_particles(const SphParams& p, const SphRiver& r, const float* T, size_t nRequested, uint32_t seed,
+                                  std::vector<SphParticle>& out, float& massOut) {
+    const float spacing = p.param_h * 0.85f;
+    massOut = p.param_restDensity * spacing * spacing * spacing;
+    Pcg32 rng(seed);
+    const float jl = -spacing * p.param_jitterAmp, jh = spacing * p.param_jitterAmp;
+    auto jitter = [&]() { return p.param_useJitter ? rng.uniform(jl, jh) : 0.0f; };
+    auto record = [&](float x, float y, float z, float vz) {
+        SphParticle q;
+        std::memset(&q, 0, sizeof(q));
+        q.pos[0] = x; q.pos[1] = y; q.pos[2] = z;
+        q.vel[2] = vz;
+        q.padC = int(out.size() & 1u);                                         // isGhost = isActive = 0, padC = count & 1
+        out.push_back(q);
+    };
+    out.clear();
+    const float zEnd = r.terrainWorldMinZ + r.terrainWorldSizeZ - spacing;
+    for (float wz = r.terrainWorldMinZ + spacing; wz < zEnd && out.size() < nRequested; wz += spacing) {
+        const float cX = p.param_boxCenter[0] + r.riverAmp * std::sin(r.riverFreq * wz + r.riverPhase);
+        for (float wx = cX - r.riverChannelWidth; wx <= cX + r.riverChannelWidth && out.size() < nRequested; wx += spacing) {
+            const float ty = river_sample_host(r, T, wx, wz);
+            for (float wy = ty + spacing; wy <= ty + 2.5f && out.size() < nRequested; wy += spacing) {
+                const float jx = jitter(), jy = jitter(), jz = jitter();
+                record(wx + jx, wy + jy, wz + jz, 0.5f);
+            }
+        }
+    }
+    const float hw = r.riverChannelWidth * 0.5f;
+    while (out.size() < nRequested) {                                          // :144-159
+        const float wx = r.riverEmitterPos[0] + rng.uniform(-hw, hw);
+        const float wz = r.riverEmitterPos[2] + rng.uniform(-hw, hw);
+        const float ty = river_sample_host(r, T, wx, wz);
+        const float up = rng.uniform(0.0f, 1.5f);
+        record(wx, ty + up, wz, 2.0f);
+    }
+}
+
 }  // namespace sph

@@ -317,6 +317,108 @@ __global__ __launch_bounds__(kBlock) void k_fountain(FountainK f, float4* __rest
     }
 }
 
+// River / stream mode: shaders/TerrainConstraints.comp, ChannelConstraint.comp and StreamEmit.comp (DispatchCompute
+// step 5, SPHFluid3D.cpp:511-516) on the SPH pass's output state.  Three dispatches in the reference; each touches only
+// its own particle, so one kernel applies them in the same order.  mix(a, b, t) = a (1 - t) + b t, normalize = v / sqrt(dot),
+// sin / cos = sph_sinf / sph_cosf (the oracle's definitions).
+struct RiverK {
+    int W, H;
+    float minX, minZ, sizeX, sizeZ;            // terrainMin / terrainSize
+    float restitution, oneMinusFriction;       // 0.02, 1 - 0.05 (:554-555)
+    float centerX, amp, freq, phase, width;    // boxCenterX, riverAmp, riverFreq, riverPhase, channelWidth
+    float flowGravity, dt;                     // 80, param_timeStep (:572-573)
+    float sinkY, sinkZMax, ex, ey, ez, evx, evy, evz, radius, spreadZ, rho0;   // :583-591
+};
+__device__ __forceinline__ float river_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float river_height(const RiverK& r, const float* __restrict__ T, float wx, float wz) {   // TerrainConstraints.comp:21-34
+    float u = (wx - r.minX) / r.sizeX * (float)(r.W - 1);
+    float v = (wz - r.minZ) / r.sizeZ * (float)(r.H - 1);
+    u = clampf(u, 0.0f, (float)(r.W - 2));
+    v = clampf(v, 0.0f, (float)(r.H - 2));
+    const int ix = (int)u, iz = (int)v;
+    const float fx = u - (float)ix, fz = v - (float)iz;
+    const float* a = T + iz * r.W + ix;
+    const float* b = a + r.W;
+    return river_mix(river_mix(a[0], a[1], fx), river_mix(b[0], b[1], fx), fz);
+}
+__global__ __launch_bounds__(kBlock) void k_river(RiverK r, const float* __restrict__ T, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                  float2* __restrict__ rp, float4* __restrict__ acc, SphParticle* __restrict__ aos,
+                                                  SphParticle* __restrict__ aosW, uint32_t idBase, int n) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const float4 P = pos[s];
+    if (fbits(P.w) & F_GHOST1) return;                       // flags.x == 1 in all three shaders
+    const float4 V = vel[s];
+    const uint32_t id = fbits(V.w);
+    float px = P.x, py = P.y, pz = P.z, vx = V.x, vy = V.y, vz = V.z;
+    // ---- TerrainConstraints.comp:50-80 ----
+    if (!(px < r.minX || px > r.minX + r.sizeX || pz < r.minZ || pz > r.minZ + r.sizeZ)) {
+        const float ty = river_height(r, T, px, pz);
+        if (py < ty) {
+            const float ddx = r.sizeX / (float)(r.W - 1), ddz = r.sizeZ / (float)(r.H - 1);
+            const float hR = river_height(r, T, px + ddx, pz), hL = river_height(r, T, px - ddx, pz);
+            const float hF = river_height(r, T, px, pz + ddz), hB = river_height(r, T, px, pz - ddz);
+            const float nx = hL - hR, ny = 2.0f * ddx, nz = hB - hF;
+            const float nl = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+            const float Nx = nx / nl, Ny = ny / nl, Nz = nz / nl;
+            py = ty + 0.001f;
+            const float vN = dot3(vx, vy, vz, Nx, Ny, Nz);
+            if (vN < 0.0f) {
+                const float ax = vN * Nx, ay = vN * Ny, az = vN * Nz;
+                const float tx = vx - ax, tyv = vy - ay, tz = vz - az;
+                vx = -r.restitution * ax + r.oneMinusFriction * tx;
+                vy = -r.restitution * ay + r.oneMinusFriction * tyv;
+                vz = -r.restitution * az + r.oneMinusFriction * tz;
+            }
+        }
+    }
+    // ---- ChannelConstraint.comp:27-46 ----
+    {
+        const float arg = r.freq * pz + r.phase;
+        const float cx = r.centerX + r.amp * sph_sinf(arg);
+        const float dx = px - cx;
+        const float tdx = r.amp * r.freq * sph_cosf(arg);
+        const float tlen = sqrtf(tdx * tdx + 1.0f);
+        vx = vx + (tdx / tlen) * r.flowGravity * r.dt;
+        vz = vz + (1.0f / tlen) * r.flowGravity * r.dt;
+        if (fabsf(dx) > r.width) {
+            px = cx + signf(dx) * r.width;
+            if (dx * vx > 0.0f) vx = 0.0f;
+        }
+    }
+    // ---- StreamEmit.comp:31-60 ----
+    const bool dead = (py < r.sinkY) || (pz > r.sinkZMax);
+    if (dead) {
+        uint32_t seed = id * 1664525u + 1013904223u;
+        const float r1 = (float)(seed & 0xFFFFu) / 65535.0f;
+        seed = seed * 1664525u + 1013904223u;                // r2: drawn, unused
+        seed = seed * 1664525u + 1013904223u;
+        const float r3 = (float)(seed & 0xFFFFu) / 65535.0f;
+        seed = seed * 1664525u + 1013904223u;
+        const float r4 = (float)(seed & 0xFFFFu) / 65535.0f;
+        const float spawnZ = r.ez + r1 * r.spreadZ;
+        const float cx = r.centerX + r.amp * sph_sinf(r.freq * spawnZ + r.phase);
+        px = cx + (r4 - 0.5f) * 2.0f * r.radius;
+        py = r.ey + r3 * 0.6f;
+        pz = spawnZ;
+        vx = r.evx; vy = r.evy; vz = r.evz;
+        rp[s] = make_float2(r.rho0, 0.0f);
+        if (acc) acc[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        reinterpret_cast<float*>(aosW + (id - idBase))[7] = 0.0f;             // p.vel = vec4(emitterVel, 0.0): the record's vel.w
+    }
+    pos[s] = make_float4(px, py, pz, P.w);
+    vel[s] = make_float4(vx, vy, vz, V.w);
+    if (aos) {
+        float* rec = reinterpret_cast<float*>(aos + (id - idBase));
+        rec[0] = px; rec[1] = py; rec[2] = pz;
+        rec[4] = vx; rec[5] = vy; rec[6] = vz;
+        if (dead) {
+            *reinterpret_cast<float4*>(rec + 8) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            rec[12] = r.rho0; rec[13] = 0.0f;
+        }
+    }
+}
+
 // Render-side export: what the reference's particle renderers read from the SSBO
 // (fluidDepth.vert / particleImpostor.vert: pos, padA foam, density, |vel|, padB dye), packed as one float4
 // per particle in ORIGINAL order, so that a renderer can map its vertex buffer once and never touch the

@@ -60,6 +60,15 @@ class SphFountain(C.Structure):
                 ("fountainDrainPerSec", C.c_float), ("fountainSeed", C.c_uint32)]
 
 
+class SphRiver(C.Structure):
+    """river / terrain members of the reference class (SPHFluid3D.h:171-196), same names."""
+    _fields_ = [("riverMode", C.c_int32), ("terrainW", C.c_int32), ("terrainH", C.c_int32),
+                ("terrainWorldMinX", C.c_float), ("terrainWorldMinZ", C.c_float), ("terrainWorldSizeX", C.c_float), ("terrainWorldSizeZ", C.c_float),
+                ("riverEmitterPos", C.c_float * 3), ("riverEmitterVel", C.c_float * 3), ("riverEmitterRadius", C.c_float),
+                ("riverSinkY", C.c_float), ("riverSinkZMax", C.c_float), ("riverAmp", C.c_float), ("riverFreq", C.c_float),
+                ("riverPhase", C.c_float), ("riverChannelWidth", C.c_float), ("riverChannelDepth", C.c_float), ("riverSlopeDrop", C.c_float)]
+
+
 class SphGridInfo(C.Structure):
     _fields_ = [("dims", C.c_int32 * 3), ("numCells", C.c_int32), ("gridMin", C.c_float * 3), ("cellSize", C.c_float)]
 
@@ -81,6 +90,7 @@ ABI_SYMBOLS = (
     "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
     "sph_slab_alloc_faces", "sph_slab_face_buffer", "sph_slab_pack_async", "sph_slab_unpack_async", "sph_slab_status",
     "sph_comm_unique_id", "sph_comm_create", "sph_comm_destroy", "sph_slab_exchange",
+    "sph_river_default", "sph_generate_river_terrain", "sph_spawn_river_particles", "sph_set_river", "sph_get_river",
 )
 # sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_list, summed over launches
 STAMP_NAMES = ("slow_waves", "slow_targets", "list_entries", "window_candidates", "lanes", "overflow_targets", "far_targets", "waves_with_fallback")
@@ -170,9 +180,14 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int]
     L.sph_comm_destroy.argtypes = [vp]
     L.sph_slab_exchange.argtypes = [vp, vp]
+    L.sph_river_default.argtypes = [C.POINTER(SphRiver)]
+    L.sph_generate_river_terrain.argtypes = [pp, C.c_int, C.POINTER(SphRiver), vp]
+    L.sph_spawn_river_particles.argtypes = [pp, C.POINTER(SphRiver), vp, C.c_size_t, C.c_uint32, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]
+    L.sph_set_river.argtypes = [vp, C.POINTER(SphRiver), vp]
+    L.sph_get_river.argtypes = [vp, C.POINTER(SphRiver)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version", "sph_fountain_default"):
+        if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version", "sph_fountain_default", "sph_river_default"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -227,7 +242,36 @@ def spawn_particles(p: SphParams, n_requested: int, seed: int):
     return buf[: n.value].copy(), float(mass.value)
 
 
+def default_river(**kw) -> SphRiver:
+    r = SphRiver()
+    load_library().sph_river_default(C.byref(r))
+    for k, v in kw.items():
+        setattr(r, k, v)
+    return r
+
+
+def generate_river_terrain(p: SphParams, seed: int, river: SphRiver | None = None):
+    """GenerateRiverTerrain (SPHFluid3D.cpp:772-878) as a pure host function: fills `river`, returns (river, heights);
+    writes param_gravityY / Z of `p` like the reference."""
+    r = river if river is not None else default_river()
+    heights = np.zeros(r.terrainW * r.terrainH, np.float32)
+    _check(load_library().sph_generate_river_terrain(C.byref(p), int(seed), C.byref(r), heights.ctypes.data_as(C.c_void_p)))
+    return r, heights
+
+
+def spawn_river_particles(p: SphParams, river: SphRiver, heights: np.ndarray, n_requested: int, seed: int):
+    """The river branch of InitializeParticles (SPHFluid3D.cpp:104-160)."""
+    h = np.ascontiguousarray(heights, np.float32)
+    buf = np.zeros(max(n_requested, 1), PARTICLE_DTYPE)
+    n = C.c_size_t()
+    mass = C.c_float()
+    _check(load_library().sph_spawn_river_particles(C.byref(p), C.byref(river), h.ctypes.data_as(C.c_void_p), n_requested, seed,
+                                                    buf.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(mass)))
+    return buf[: n.value].copy(), float(mass.value)
+
+
 _PARAM_NAMES = {f[0] for f in SphParams._fields_}
+_RIVER_NAMES = {f[0] for f in SphRiver._fields_}
 _FOUNTAIN_NAMES = {f[0] for f in SphFountain._fields_}
 
 
@@ -246,6 +290,10 @@ class SPHFluidGPU:
         object.__setattr__(self, "_h", C.c_void_p())
         object.__setattr__(self, "_f", SphFountain())
         L.sph_fountain_default(C.byref(self._f))
+        object.__setattr__(self, "_r", SphRiver())
+        L.sph_river_default(C.byref(self._r))
+        object.__setattr__(self, "terrainHeights", np.zeros(0, np.float32))   # SPHFluid3D.h:175
+        object.__setattr__(self, "_terrain_sent", None)
         object.__setattr__(self, "numParticles", int(numParticles_))
         object.__setattr__(self, "seed", int(seed))
         if _particles is not None:
@@ -261,14 +309,14 @@ class SPHFluidGPU:
 
     # -- public param_* members ----------------------------------------------------------
     def __getattr__(self, name):
-        if name in _PARAM_NAMES or name in _FOUNTAIN_NAMES:
-            v = getattr(object.__getattribute__(self, "_p" if name in _PARAM_NAMES else "_f"), name)
+        if name in _PARAM_NAMES or name in _FOUNTAIN_NAMES or name in _RIVER_NAMES:
+            v = getattr(object.__getattribute__(self, "_p" if name in _PARAM_NAMES else ("_f" if name in _FOUNTAIN_NAMES else "_r")), name)
             return list(v) if hasattr(v, "__len__") else v
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if name in _PARAM_NAMES or name in _FOUNTAIN_NAMES:
-            st = self._p if name in _PARAM_NAMES else self._f
+        if name in _PARAM_NAMES or name in _FOUNTAIN_NAMES or name in _RIVER_NAMES:
+            st = self._p if name in _PARAM_NAMES else (self._f if name in _FOUNTAIN_NAMES else self._r)
             cur = getattr(st, name)
             if hasattr(cur, "__len__"):
                 for i, x in enumerate(value):
@@ -286,6 +334,31 @@ class SPHFluidGPU:
     def _push_members(self):
         _check(self._L.sph_set_params(self._h, C.byref(self._p)))  # members are re-read every dispatch (:458-506)
         _check(self._L.sph_set_fountain(self._h, C.byref(self._f)))  # fountain* members (:519-541)
+        self._push_river()
+
+    def _push_river(self):                                           # river members (:511-516); the heightfield only when it changed
+        th = self.terrainHeights
+        fresh = th is not self._terrain_sent and len(th) > 0
+        ptr = None
+        if fresh:
+            th = np.ascontiguousarray(th, np.float32)
+            if len(th) != self._r.terrainW * self._r.terrainH:
+                raise SphError(f"terrainHeights has {len(th)} samples, terrainW x terrainH = {self._r.terrainW * self._r.terrainH}")
+            ptr = th.ctypes.data_as(C.c_void_p)
+        _check(self._L.sph_set_river(self._h, C.byref(self._r), ptr))
+        if fresh:
+            object.__setattr__(self, "_terrain_sent", self.terrainHeights)
+
+    def set_river(self, river: SphRiver, heights):                   # all river members + terrainHeights in one go
+        C.memmove(C.byref(self._r), C.byref(river), C.sizeof(SphRiver))
+        object.__setattr__(self, "terrainHeights", np.ascontiguousarray(heights, np.float32).copy())
+        self._push_river()
+
+    def GenerateRiverTerrain(self, seed: int):                       # SPHFluid3D.cpp:772-878
+        heights = np.zeros(self._r.terrainW * self._r.terrainH, np.float32)
+        _check(self._L.sph_generate_river_terrain(C.byref(self._p), int(seed), C.byref(self._r), heights.ctypes.data_as(C.c_void_p)))
+        object.__setattr__(self, "terrainHeights", heights)
+        self._push_river()
 
     def DispatchCompute(self, overrideDt: float = -1.0):            # SPHFluid3D.cpp:431
         self._push_members()
@@ -303,6 +376,7 @@ class SPHFluidGPU:
         if seed is not None:
             self.seed = int(seed)
         _check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        self._push_river()                                           # riverMode && !terrainHeights.empty() picks the spawn branch (:104)
         _check(self._L.sph_reset(self._h, self.numParticles, self.seed))
         _check(self._L.sph_get_params(self._h, C.byref(self._p)))
 

@@ -50,7 +50,21 @@ int main(int argc, char** argv) {
     std::printf("%d substeps in %.3f ms (%.1f substeps/s)\n", nSub, ms, nSub / ms * 1e3);
     fluidGPU->numParticles = 20000;
     fluidGPU->ResetSimulation();
-    const bool ok = fluidGPU->GetNumFluids() == 20000 && fluidGPU->LastError().empty() && std::isfinite(rho);
+    bool ok = fluidGPU->GetNumFluids() == 20000 && fluidGPU->LastError().empty() && std::isfinite(rho);
+    // river / stream mode (SPHFluid3D.h:171-206; dead code in Scene0p, driven here the way its members are meant to be)
+    fluidGPU->param_boxEulerDeg = Vec3(0.0f, 0.0f, 0.0f);
+    fluidGPU->GenerateRiverTerrain(3);
+    fluidGPU->riverMode = true;
+    fluidGPU->ResetSimulation();
+    for (int i = 0; i < 40; ++i) fluidGPU->DispatchCompute(fixedDt);
+    if (!fluidGPU->Download(host)) { delete fluidGPU; return 3; }
+    size_t inChannel = 0;
+    for (const auto& p : host) {
+        const float cx = fluidGPU->param_boxCenter.x + fluidGPU->riverAmp * std::sin(fluidGPU->riverFreq * p.pos.z + fluidGPU->riverPhase);
+        if (std::fabs(p.pos.x - cx) <= fluidGPU->riverChannelWidth * 1.001f && std::isfinite(p.pos.y)) ++inChannel;
+    }
+    std::printf("river mode: %zu of %zu particles inside the channel after 40 substeps\n", inChannel, host.size());
+    ok = ok && inChannel == host.size() && fluidGPU->LastError().empty() && fluidGPU->param_gravityY == -120.0f;
     delete fluidGPU;
     std::printf(ok ? "headless_scene OK\n" : "headless_scene FAILED\n");
     return ok ? 0 : 1;

@@ -65,14 +65,16 @@ public:
         SphFountain f{fountainMode ? 1 : 0, {fountainOffset.x, fountainOffset.y, fountainOffset.z}, fountainRadius, fountainSpread,
                       fountainJetSpeedLive, fountainDrainLevel, fountainDrainPerSec, fountainSeed};
         if (Check(sph_set_fountain(engine, &f), "sph_set_fountain")) return;
+        if (PushRiver()) return;                                        // river members, step 5 (:511-516)
         if (Check(sph_dispatch(engine, overrideDt), "sph_dispatch")) return;
-        if (fountainMode && !param_pause) ++fountainSeed;               // glUniform1ui("uSeed", fountainSeed++), :541
+        if (fountainMode && !riverMode && !param_pause) ++fountainSeed; // glUniform1ui("uSeed", fountainSeed++), :541 (fountain step only `!riverMode`, :519)
         RefreshGrid();
     }
     void SimulateSubstep(float overrideDt = -1.0f) { DispatchCompute(overrideDt); }   // BASELINE.json's name
     void ResetSimulation() {                                            // SPHFluid3D.cpp:713
         SphParams p = ToParams();
         if (Check(sph_set_params(engine, &p), "sph_set_params")) return;
+        if (PushRiver()) return;                                        // riverMode && !terrainHeights.empty() selects the spawn branch (:104)
         if (Check(sph_reset(engine, numParticles, seed), "sph_reset")) return;
         AfterSpawn();
         std::printf("Reset: particles=%zu fluids=%zu grid=%dx%dx%d cells=%d\n", particles.size(), numFluids, gridSizeX, gridSizeY, gridSizeZ, numCells);
@@ -100,6 +102,22 @@ public:
     }
     void ApplyStencilAttract(float pullKick, float dampKick) {           // SPHFluid3D.cpp:695
         Check(sph_apply_stencil_attract(engine, pullKick, dampKick), "sph_apply_stencil_attract");
+    }
+    void GenerateRiverTerrain(int seed_) {                               // SPHFluid3D.cpp:772-878 (heightfield upload = sph_set_river)
+        SphParams p = ToParams();
+        SphRiver r = ToRiver();
+        terrainHeights.assign(size_t(terrainW) * size_t(terrainH), 0.0f);
+        if (Check(sph_generate_river_terrain(&p, seed_, &r, terrainHeights.data()), "sph_generate_river_terrain")) return;
+        param_gravityY = p.param_gravityY; param_gravityZ = p.param_gravityZ;   // :864-865
+        terrainWorldMinX = r.terrainWorldMinX; terrainWorldMinZ = r.terrainWorldMinZ;
+        terrainWorldSizeX = r.terrainWorldSizeX; terrainWorldSizeZ = r.terrainWorldSizeZ;
+        riverEmitterPos = MATH::Vec3(r.riverEmitterPos[0], r.riverEmitterPos[1], r.riverEmitterPos[2]);
+        riverEmitterVel = MATH::Vec3(r.riverEmitterVel[0], r.riverEmitterVel[1], r.riverEmitterVel[2]);
+        riverEmitterRadius = r.riverEmitterRadius; riverSinkY = r.riverSinkY; riverSinkZMax = r.riverSinkZMax;
+        riverAmp = r.riverAmp; riverFreq = r.riverFreq; riverPhase = r.riverPhase;
+        riverChannelWidth = r.riverChannelWidth; riverChannelDepth = r.riverChannelDepth; riverSlopeDrop = r.riverSlopeDrop;
+        terrainDirty = true;
+        std::printf("[River] seed=%d amp=%g freq=%g width=%g slope=%g\n", seed_, riverAmp, riverFreq, riverChannelWidth, riverSlopeDrop);
     }
     int stencilCount = 0;                                                // SPHFluid3D.h:55
     MATH::Vec3 EffectiveHalf() const {                                  // SPHFluid3D.h:127
@@ -169,11 +187,20 @@ public:
     int param_dyePattern = 0;
     float param_wallRestitution = 0.15f;
     float param_wallFriction = 0.02f;
-    // inert counterparts of members Scene0p touches (SPHFluid3D.h:72 `ssbo`: bound as binding 0 by the GL renderers,
-    // Scene0p.cpp:1625,2627,3065,3142 -- 0 binds nothing; SPHFluid3D.h:172 `riverMode`: only ever written false,
-    // Scene0p.cpp:1660 -- the river branch of DispatchCompute, SPHFluid3D.cpp:512-516, is dead code and not built)
+    // inert counterpart of a member Scene0p touches (SPHFluid3D.h:72 `ssbo`: bound as binding 0 by the GL renderers,
+    // Scene0p.cpp:1625,2627,3065,3142 -- 0 binds nothing)
     unsigned int ssbo = 0;
+    // river / stream mode, SPHFluid3D.h:171-196 (step 5 of DispatchCompute, :511-516; Scene0p only ever writes
+    // riverMode = false, Scene0p.cpp:1660).  After editing terrainHeights by hand set terrainDirty.
     bool riverMode = false;
+    std::vector<float> terrainHeights;
+    int terrainW = 64, terrainH = 64;
+    float terrainWorldMinX = -7.0f, terrainWorldMinZ = -10.0f, terrainWorldSizeX = 14.0f, terrainWorldSizeZ = 20.0f;
+    MATH::Vec3 riverEmitterPos = MATH::Vec3(0.0f, 3.0f, -9.0f);
+    MATH::Vec3 riverEmitterVel = MATH::Vec3(0.0f, -0.5f, 4.0f);
+    float riverEmitterRadius = 1.5f, riverSinkY = -8.5f, riverSinkZMax = 9.0f;
+    float riverAmp = 2.0f, riverFreq = 0.25f, riverPhase = 0.0f, riverChannelWidth = 3.0f, riverChannelDepth = 3.5f, riverSlopeDrop = 0.3f;
+    bool terrainDirty = false;                 // engine extension: terrainHeights changed since the last upload
     // fountain members, SPHFluid3D.h:161-168 (step 6 of DispatchCompute, :519)
     bool fountainMode = false;
     MATH::Vec3 fountainOffset = MATH::Vec3(0.0f, -5.0f, 0.0f);
@@ -191,6 +218,19 @@ private:
     void* stream = nullptr;
     std::string lastError;
 
+    SphRiver ToRiver() const {
+        return SphRiver{riverMode ? 1 : 0, terrainW, terrainH, terrainWorldMinX, terrainWorldMinZ, terrainWorldSizeX, terrainWorldSizeZ,
+                        {riverEmitterPos.x, riverEmitterPos.y, riverEmitterPos.z}, {riverEmitterVel.x, riverEmitterVel.y, riverEmitterVel.z},
+                        riverEmitterRadius, riverSinkY, riverSinkZMax, riverAmp, riverFreq, riverPhase, riverChannelWidth, riverChannelDepth,
+                        riverSlopeDrop};
+    }
+    bool PushRiver() {                         // true on error
+        const SphRiver r = ToRiver();
+        const bool send = terrainDirty && terrainHeights.size() == size_t(terrainW) * size_t(terrainH);
+        if (Check(sph_set_river(engine, &r, send ? terrainHeights.data() : nullptr), "sph_set_river")) return true;
+        if (send) terrainDirty = false;
+        return false;
+    }
     SphParams ToParams() const {
         SphParams p;
         sph_params_default(&p);

@@ -107,11 +107,22 @@ typedef struct SphFountain {       /* public fountain* members of SPHFluidGPU, S
     uint32_t fountainSeed;         /* advances by one per dispatch (SPHFluid3D.cpp:541) */
 } SphFountain;
 
+typedef struct SphRiver {          /* public river / terrain members of SPHFluidGPU, SPHFluid3D.h:171-196 (same names, same initialisers) */
+    int32_t riverMode;             /* bool riverMode = false */
+    int32_t terrainW, terrainH;    /* 64, 64: heightfield samples; the heights themselves travel beside this struct */
+    float terrainWorldMinX, terrainWorldMinZ, terrainWorldSizeX, terrainWorldSizeZ;   /* -7, -10, 14, 20 */
+    float riverEmitterPos[3];      /* (0, 3, -9) */
+    float riverEmitterVel[3];      /* (0, -0.5, 4) */
+    float riverEmitterRadius;      /* 1.5 */
+    float riverSinkY, riverSinkZMax;   /* -8.5, 9 */
+    float riverAmp, riverFreq, riverPhase, riverChannelWidth, riverChannelDepth, riverSlopeDrop;   /* 2, 0.25, 0, 3, 3.5, 0.3 */
+} SphRiver;
+
 typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHFluidGPU owns its GL buffers, SPHFluid3D.cpp:61-83) */
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
 enum {
-    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = k_sph_list (default: two targets per lane, LDS-staged candidate rows, neighbour lists), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = k_sph_list (default: one target per lane, LDS-staged candidate rows, neighbour lists), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
@@ -188,6 +199,27 @@ int sph_apply_curl_flow(SphEngine* e, float kick, float scale, float time);
 void sph_fountain_default(SphFountain* out);             /* SPHFluid3D.h:161-168 initialisers */
 int sph_set_fountain(SphEngine* e, const SphFountain* f);
 int sph_get_fountain(const SphEngine* e, SphFountain* out);
+
+/* River / stream mode = DispatchCompute step 5 (SPHFluid3D.cpp:511-516: DispatchTerrainConstraints :546-560,
+ * DispatchChannelConstraint :562-578, DispatchStreamEmit :580-602 with shaders/TerrainConstraints.comp,
+ * ChannelConstraint.comp, StreamEmit.comp): while riverMode is set and a heightfield has been given, every dispatch
+ * ends with terrain collision, channel confinement and recycling (one fused kernel: each pass touches only its own
+ * particle); the fountain step is then skipped (:519) and sph_reset spawns along the channel (:104-160).  Dead code in
+ * the reference's scene (Scene0p.cpp:1660 is the only writer of riverMode), provided for completeness.
+ * Single-GPU engines only (recycled particles jump across slabs). */
+void sph_river_default(SphRiver* out);                   /* SPHFluid3D.h:171-196 initialisers */
+/* SPHFluidGPU::GenerateRiverTerrain(int seed), SPHFluid3D.cpp:772-878, as a pure host function: reads
+ * params->param_boxCenter / param_boxHalf and river->terrainW / terrainH; writes every other member of *river,
+ * terrainW * terrainH floats into `heights` (terrainHeights) and param_gravityY = -120, param_gravityZ = 0 (:864-865).
+ * std::rand() is the Microsoft runtime's LCG (the reference is a Visual Studio project). */
+int sph_generate_river_terrain(SphParams* params, int seed, SphRiver* river, float* heights);
+/* The river branch of InitializeParticles (:104-160) as a pure host function; writes exactly nRequested records. */
+int sph_spawn_river_particles(const SphParams* params, const SphRiver* river, const float* heights, size_t nRequested,
+                              uint32_t seed, SphParticle* out, size_t* nOut, float* massOut);
+/* Members + heightfield into the engine (the glBufferData of terrainSSBO, :868-873).  heights == NULL keeps the
+ * heightfield given before (terrainW / terrainH must then be unchanged). */
+int sph_set_river(SphEngine* e, const SphRiver* river, const float* heights);
+int sph_get_river(const SphEngine* e, SphRiver* out);
 
 /* ---- data ------------------------------------------------------------------------ */
 size_t sph_num_particles(const SphEngine* e);            /* particles.size() / GetNumFluids() */

@@ -239,6 +239,68 @@ def fountain_recycle(P: np.ndarray, p: OParams, f: OFountain, dt: float, seed: i
     return out
 
 
+class ORiver(C.Structure):
+    """river / terrain members of SPHFluidGPU (SPHFluid3D.h:171-196), same names."""
+    _fields_ = [("riverMode", C.c_int32), ("terrainW", C.c_int32), ("terrainH", C.c_int32),
+                ("terrainWorldMinX", C.c_float), ("terrainWorldMinZ", C.c_float), ("terrainWorldSizeX", C.c_float), ("terrainWorldSizeZ", C.c_float),
+                ("riverEmitterPos", C.c_float * 3), ("riverEmitterVel", C.c_float * 3), ("riverEmitterRadius", C.c_float),
+                ("riverSinkY", C.c_float), ("riverSinkZMax", C.c_float), ("riverAmp", C.c_float), ("riverFreq", C.c_float),
+                ("riverPhase", C.c_float), ("riverChannelWidth", C.c_float), ("riverChannelDepth", C.c_float), ("riverSlopeDrop", C.c_float)]
+
+
+def default_river(**kw) -> ORiver:
+    r = ORiver()
+    L = lib()
+    L.sph_oracle_river_default.restype = None
+    L.sph_oracle_river_default(C.byref(r))
+    for k, v in kw.items():
+        setattr(r, k, v)
+    return r
+
+
+def river_terrain(p: OParams, seed: int, river: "ORiver | None" = None):
+    """GenerateRiverTerrain (SPHFluid3D.cpp:772-878): fills the river members, returns (river, heights); writes p.gravity."""
+    r = river if river is not None else default_river()
+    heights = np.zeros(r.terrainW * r.terrainH, np.float32)
+    L = lib()
+    L.sph_oracle_river_terrain.restype = None
+    L.sph_oracle_river_terrain(C.byref(p), C.c_int(seed), C.byref(r), heights.ctypes.data_as(C.c_void_p))
+    return r, heights
+
+
+def river_spawn(p: OParams, r: ORiver, heights: np.ndarray, n_requested: int, seed: int):
+    """InitializeParticles, river branch (SPHFluid3D.cpp:104-160)."""
+    out = np.zeros(max(n_requested, 1), PARTICLE_DTYPE)
+    mass = C.c_float()
+    h = np.ascontiguousarray(heights, np.float32)
+    L = lib()
+    L.sph_oracle_river_spawn.restype = C.c_int
+    n = L.sph_oracle_river_spawn(C.byref(p), C.byref(r), h.ctypes.data_as(C.c_void_p), C.c_int(n_requested), C.c_uint32(seed), _ptr(out), C.byref(mass))
+    return out[:n].copy(), float(mass.value)
+
+
+def river_step(P: np.ndarray, p: OParams, r: ORiver, heights: np.ndarray) -> np.ndarray:
+    """Step 5 of DispatchCompute alone: terrain, channel, emit."""
+    out = P.copy()
+    h = np.ascontiguousarray(heights, np.float32)
+    L = lib()
+    L.sph_oracle_river.restype = None
+    L.sph_oracle_river(_ptr(out), len(out), C.byref(p), C.byref(r), h.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def substep_river(P: np.ndarray, p: OParams, r: ORiver, heights: np.ndarray, dt: float = -1.0, steps: int = 1) -> np.ndarray:
+    """DispatchCompute x steps in river mode (SPHFluid3D.cpp:431-522 with step 5, without the fountain step)."""
+    cur = P.copy()
+    scratch = np.zeros_like(cur)
+    h = np.ascontiguousarray(heights, np.float32)
+    L = lib()
+    L.sph_oracle_substep_river.restype = None
+    for _ in range(steps):
+        L.sph_oracle_substep_river(_ptr(cur), _ptr(scratch), len(cur), C.byref(p), C.c_float(dt), C.byref(r), h.ctypes.data_as(C.c_void_p))
+    return cur
+
+
 def wave_impulse(P, amplitude, wavelength, phase, direction, y_min=-3.4028235e38, y_max=3.4028235e38):
     out = P.copy()
     lib().sph_oracle_wave_impulse(_ptr(out), len(out), amplitude, wavelength, phase, f3(direction), y_min, y_max)

@@ -1392,3 +1392,245 @@ void sph_oracle_curl_flow(OParticle* P, int n, float kick, float scale, float ti
         p->vel[2] = p->vel[2] + (dz * mm) * kick;
     }
 }
+
+/* ====================================================================================
+ * River / stream mode (SPHFluid3D.h:171-206): GenerateRiverTerrain (SPHFluid3D.cpp:772-878), the river branch of
+ * InitializeParticles (:104-160) and step 5 of DispatchCompute (:511-516: TerrainConstraints.comp,
+ * ChannelConstraint.comp, StreamEmit.comp, in that order; the fountain step is skipped while riverMode is set, :519).
+ * Dead code in the reference's scene (riverMode is never set, Scene0p.cpp:1660), restated for completeness.
+ *
+ * Semantic 11: std::rand() / RAND_MAX in GenerateRiverTerrain is the Microsoft C runtime's (the reference is a
+ *   Visual Studio project, ComponentFramework.vcxproj): holdrand = holdrand * 214013 + 2531011, result
+ *   (holdrand >> 16) & 0x7fff, RAND_MAX 0x7fff, srand(seed) sets holdrand = seed.  Host-side sinf / cosf are libm's
+ *   (host code in the reference too).
+ * Semantic 12: GLSL mix(a, b, t) = a * (1 - t) + b * t as the specification writes it; normalize(v) = v / sqrt(dot);
+ *   sin / cos in the shaders = the specified sph_oracle_sinf / sph_oracle_cosf (semantics 6 and 10).
+ * Semantic 13: the jitter / fill random numbers of the spawn come from the same PCG32 stream as the standard fill
+ *   (semantic: default_random_engine(time(nullptr)) is not reproducible in the reference either).
+ * ==================================================================================== */
+
+typedef struct {
+    int32_t riverMode;                                        /* SPHFluid3D.h:172 */
+    int32_t terrainW, terrainH;                               /* :176-177 */
+    float terrainWorldMinX, terrainWorldMinZ, terrainWorldSizeX, terrainWorldSizeZ;   /* :178-181 */
+    float riverEmitterPos[3], riverEmitterVel[3];             /* :184-185 */
+    float riverEmitterRadius, riverSinkY, riverSinkZMax;      /* :186-188 */
+    float riverAmp, riverFreq, riverPhase, riverChannelWidth, riverChannelDepth, riverSlopeDrop;   /* :191-196 */
+} ORiver;
+
+int sph_oracle_sizeof_river(void) { return (int)sizeof(ORiver); }
+
+void sph_oracle_river_default(ORiver* r) {
+    memset(r, 0, sizeof(*r));
+    r->terrainW = 64; r->terrainH = 64;
+    r->terrainWorldMinX = -7.0f; r->terrainWorldMinZ = -10.0f; r->terrainWorldSizeX = 14.0f; r->terrainWorldSizeZ = 20.0f;
+    r->riverEmitterPos[0] = 0.0f; r->riverEmitterPos[1] = 3.0f; r->riverEmitterPos[2] = -9.0f;
+    r->riverEmitterVel[0] = 0.0f; r->riverEmitterVel[1] = -0.5f; r->riverEmitterVel[2] = 4.0f;
+    r->riverEmitterRadius = 1.5f; r->riverSinkY = -8.5f; r->riverSinkZMax = 9.0f;
+    r->riverAmp = 2.0f; r->riverFreq = 0.25f; r->riverPhase = 0.0f;
+    r->riverChannelWidth = 3.0f; r->riverChannelDepth = 3.5f; r->riverSlopeDrop = 0.3f;
+}
+
+static float o_msvc_frand(uint32_t* hold) {
+    *hold = *hold * 214013u + 2531011u;
+    return (float)((*hold >> 16) & 0x7fffu) / 32767.0f;      /* std::rand() / float(RAND_MAX), :774 */
+}
+
+/* GenerateRiverTerrain(seed): fills the river members, the heightfield (terrainW * terrainH floats) and sets
+ * param_gravityY = -120, param_gravityZ = 0 (:864-865). */
+void sph_oracle_river_terrain(OParams* p, int seed, ORiver* r, float* heights) {
+    uint32_t hold = (uint32_t)seed;                                          /* :773 */
+    r->riverAmp = 0.5f + o_msvc_frand(&hold) * 1.5f;                         /* :777-782 */
+    r->riverFreq = 0.18f + o_msvc_frand(&hold) * 0.18f;
+    r->riverPhase = o_msvc_frand(&hold) * 6.2831f;
+    r->riverChannelWidth = 1.8f + o_msvc_frand(&hold) * 1.2f;
+    r->riverChannelDepth = 3.5f + o_msvc_frand(&hold) * 1.0f;
+    r->riverSlopeDrop = 0.3f + o_msvc_frand(&hold) * 0.5f;
+    const float channelDepth = r->riverChannelDepth, slopeDrop = r->riverSlopeDrop;
+    float ph[8];
+    for (int k = 0; k < 8; ++k) ph[k] = o_msvc_frand(&hold) * 6.2831f;       /* :787-788 */
+    r->terrainWorldMinX = p->boxCenter[0] - p->boxHalf[0];                   /* :792-795 */
+    r->terrainWorldMinZ = p->boxCenter[2] - p->boxHalf[2];
+    r->terrainWorldSizeX = 2.0f * p->boxHalf[0];
+    r->terrainWorldSizeZ = 2.0f * p->boxHalf[2];
+    const float xMin = r->terrainWorldMinX, zMin = r->terrainWorldMinZ, xSize = r->terrainWorldSizeX, zSize = r->terrainWorldSizeZ;
+    const float yBase = p->boxCenter[1] - p->boxHalf[1];
+    const int W = r->terrainW, H = r->terrainH;
+    for (int iz = 0; iz < H; ++iz)
+        for (int ix = 0; ix < W; ++ix) {
+            const float wx = xMin + ((float)ix / (float)(W - 1)) * xSize;   /* :807-808 */
+            const float wz = zMin + ((float)iz / (float)(H - 1)) * zSize;
+            const float tFlow = (wz - zMin) / zSize;
+            const float centerX = p->boxCenter[0] + r->riverAmp * sinf(r->riverFreq * wz + r->riverPhase);
+            const float distToRiver = fabsf(wx - centerX);
+            const float riverFloor = yBase + 1.0f - tFlow * slopeDrop;      /* :818-819 */
+            const float channelEdge = riverFloor + channelDepth;
+            float h = channelEdge + 3.0f;                                    /* :824-828 */
+            h += 0.5f * sinf(wx * 0.35f + ph[0]) * cosf(wz * 0.28f + ph[1]);
+            h += 0.25f * sinf(wx * 0.70f + ph[2]) * sinf(wz * 0.60f + ph[3]);
+            h += 0.12f * sinf(wx * 1.40f + ph[4]) * cosf(wz * 1.20f + ph[5]);
+            if (distToRiver < r->riverChannelWidth) {                        /* :830-840 */
+                const float u = distToRiver / r->riverChannelWidth;
+                if (u < 0.50f) h = riverFloor;
+                else { const float uw = (u - 0.50f) / (1.0f - 0.50f); h = riverFloor + channelDepth * uw * uw; }
+            } else {
+                h = fmaxf(h, channelEdge + 0.3f);                            /* :843 */
+            }
+            h = fmaxf(h, yBase - 0.3f);                                      /* :847 */
+            heights[iz * W + ix] = h;
+        }
+    const float emitterZ = zMin + 0.5f;                                      /* :853-861 */
+    r->riverEmitterPos[0] = p->boxCenter[0] + r->riverAmp * sinf(r->riverFreq * emitterZ + r->riverPhase);
+    r->riverEmitterPos[1] = (yBase + 1.0f) + channelDepth * 0.5f;
+    r->riverEmitterPos[2] = emitterZ;
+    r->riverEmitterVel[0] = 0.0f; r->riverEmitterVel[1] = -0.5f; r->riverEmitterVel[2] = 0.5f;
+    r->riverEmitterRadius = r->riverChannelWidth * 0.35f;
+    r->riverSinkY = yBase + 0.3f;
+    r->riverSinkZMax = p->boxCenter[2] + p->boxHalf[2] - 0.5f;
+    p->gravity[1] = -120.0f; p->gravity[2] = 0.0f;                           /* :864-865 */
+}
+
+/* host-side bilinear sample of the spawn (the lambda at :113-126; NOT the shader's mix form) */
+static float o_river_sample_host(const ORiver* r, const float* T, float wx, float wz) {
+    float u = (wx - r->terrainWorldMinX) / r->terrainWorldSizeX * (float)(r->terrainW - 1);
+    float v = (wz - r->terrainWorldMinZ) / r->terrainWorldSizeZ * (float)(r->terrainH - 1);
+    u = fmaxf(0.0f, fminf((float)(r->terrainW - 2), u));
+    v = fmaxf(0.0f, fminf((float)(r->terrainH - 2), v));
+    const int ix = (int)u, iz = (int)v, W = r->terrainW;
+    const float fx = u - (float)ix, fz = v - (float)iz;
+    const float h00 = T[ix + iz * W], h10 = T[(ix + 1) + iz * W], h01 = T[ix + (iz + 1) * W], h11 = T[(ix + 1) + (iz + 1) * W];
+    return h00 * (1 - fx) * (1 - fz) + h10 * fx * (1 - fz) + h01 * (1 - fx) * fz + h11 * fx * fz;
+}
+
+/* InitializeParticles, river branch (:104-160).  Returns the particle count (always nRequested). */
+int sph_oracle_river_spawn(const OParams* p, const ORiver* r, const float* T, int nRequested, uint32_t seed, OParticle* out, float* massOut) {
+    const float spacing = p->h * 0.85f;
+    *massOut = p->restDensity * spacing * spacing * spacing;
+    OPcg rng; o_pcg_seed(&rng, seed);
+    const float jlo = -spacing * p->jitterAmp, jhi = spacing * p->jitterAmp;
+    const float zMin = r->terrainWorldMinZ, zSize = r->terrainWorldSizeZ;
+    int count = 0;
+    for (float wz = zMin + spacing; wz < zMin + zSize - spacing && count < nRequested; wz += spacing) {
+        const float centerX = p->boxCenter[0] + r->riverAmp * sinf(r->riverFreq * wz + r->riverPhase);
+        for (float wx = centerX - r->riverChannelWidth; wx <= centerX + r->riverChannelWidth && count < nRequested; wx += spacing) {
+            const float ty = o_river_sample_host(r, T, wx, wz);
+            for (float wy = ty + spacing; wy <= ty + 2.5f && count < nRequested; wy += spacing) {
+                OParticle q; memset(&q, 0, sizeof(q));
+                const float jx = p->useJitter ? o_pcg_uniform(&rng, jlo, jhi) : 0.0f;   /* argument order of Vec4(wx + j(), wy + j(), wz + j()) */
+                const float jy = p->useJitter ? o_pcg_uniform(&rng, jlo, jhi) : 0.0f;
+                const float jz = p->useJitter ? o_pcg_uniform(&rng, jlo, jhi) : 0.0f;
+                q.pos[0] = wx + jx; q.pos[1] = wy + jy; q.pos[2] = wz + jz;
+                q.vel[2] = 0.5f;
+                q.padC = count & 1;
+                out[count++] = q;
+            }
+        }
+    }
+    while (count < nRequested) {                                             /* :144-159 */
+        const float hw = r->riverChannelWidth * 0.5f;
+        const float wx = r->riverEmitterPos[0] + o_pcg_uniform(&rng, -hw, hw);
+        const float wz = r->riverEmitterPos[2] + o_pcg_uniform(&rng, -hw, hw);
+        const float ty = o_river_sample_host(r, T, wx, wz);
+        OParticle q; memset(&q, 0, sizeof(q));
+        q.pos[0] = wx; q.pos[1] = ty + o_pcg_uniform(&rng, 0.0f, 1.5f); q.pos[2] = wz;
+        q.vel[2] = 2.0f;
+        q.padC = count & 1;
+        out[count++] = q;
+    }
+    return count;
+}
+
+/* mix(): o_mix above (semantic 12 = the definition the curl-noise restatement already uses) */
+
+/* TerrainConstraints.comp:21-34 */
+static float o_terrain_height(const ORiver* r, const float* T, float wx, float wz) {
+    float u = (wx - r->terrainWorldMinX) / r->terrainWorldSizeX * (float)(r->terrainW - 1);
+    float v = (wz - r->terrainWorldMinZ) / r->terrainWorldSizeZ * (float)(r->terrainH - 1);
+    u = o_clampf(u, 0.0f, (float)(r->terrainW - 2));
+    v = o_clampf(v, 0.0f, (float)(r->terrainH - 2));
+    const int ix = (int)u, iz = (int)v, W = r->terrainW;
+    const float fx = u - (float)ix, fz = v - (float)iz;
+    const float h00 = T[ix + iz * W], h10 = T[(ix + 1) + iz * W], h01 = T[ix + (iz + 1) * W], h11 = T[(ix + 1) + (iz + 1) * W];
+    return o_mix(o_mix(h00, h10, fx), o_mix(h01, h11, fx), fz);
+}
+
+/* Step 5 of DispatchCompute (:511-516) on every particle: the three passes touch only their own particle, in order. */
+void sph_oracle_river(OParticle* P, int n, const OParams* p, const ORiver* r, const float* T) {
+    const float restitution = 0.02f, friction = 0.05f;                      /* :554-555 */
+    const float flowGravity = 80.0f;                                        /* :572 */
+    const float dt = p->timeStep;                                           /* :573: param_timeStep, not the override */
+    const float spreadZ = r->riverSinkZMax - r->riverEmitterPos[2];         /* :590 */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        OParticle* q = &P[i];
+        if (q->isGhost == 1) continue;                                      /* all three shaders */
+        /* ---- TerrainConstraints.comp:50-80 ---- */
+        {
+            const float wx = q->pos[0], wz = q->pos[2];
+            const int inside = !(wx < r->terrainWorldMinX || wx > r->terrainWorldMinX + r->terrainWorldSizeX ||
+                                 wz < r->terrainWorldMinZ || wz > r->terrainWorldMinZ + r->terrainWorldSizeZ);
+            if (inside) {
+                const float ty = o_terrain_height(r, T, wx, wz);
+                if (q->pos[1] < ty) {
+                    const float ddx = r->terrainWorldSizeX / (float)(r->terrainW - 1), ddz = r->terrainWorldSizeZ / (float)(r->terrainH - 1);   /* :38-39 */
+                    const float hR = o_terrain_height(r, T, wx + ddx, wz), hL = o_terrain_height(r, T, wx - ddx, wz);
+                    const float hF = o_terrain_height(r, T, wx, wz + ddz), hB = o_terrain_height(r, T, wx, wz - ddz);
+                    const float nx = hL - hR, ny = 2.0f * ddx, nz = hB - hF;
+                    const float nl = sqrtf(o_dot3(nx, ny, nz, nx, ny, nz));
+                    const float Nx = nx / nl, Ny = ny / nl, Nz = nz / nl;
+                    q->pos[1] = ty + 0.001f;                                /* :66 */
+                    const float vN = o_dot3(q->vel[0], q->vel[1], q->vel[2], Nx, Ny, Nz);
+                    if (vN < 0.0f) {                                        /* :71-76 */
+                        const float ax = vN * Nx, ay = vN * Ny, az = vN * Nz;
+                        const float tx = q->vel[0] - ax, tyv = q->vel[1] - ay, tz = q->vel[2] - az;
+                        q->vel[0] = -restitution * ax + (1.0f - friction) * tx;
+                        q->vel[1] = -restitution * ay + (1.0f - friction) * tyv;
+                        q->vel[2] = -restitution * az + (1.0f - friction) * tz;
+                    }
+                }
+            }
+        }
+        /* ---- ChannelConstraint.comp:27-46 ---- */
+        {
+            const float wz = q->pos[2];
+            const float arg = r->riverFreq * wz + r->riverPhase;
+            const float cx = p->boxCenter[0] + r->riverAmp * sph_oracle_sinf(arg);
+            const float dx = q->pos[0] - cx;
+            const float tdx = r->riverAmp * r->riverFreq * sph_oracle_cosf(arg);
+            const float tlen = sqrtf(tdx * tdx + 1.0f);
+            const float tX = tdx / tlen, tZ = 1.0f / tlen;
+            q->vel[0] = q->vel[0] + tX * flowGravity * dt;
+            q->vel[2] = q->vel[2] + tZ * flowGravity * dt;
+            if (fabsf(dx) > r->riverChannelWidth) {
+                q->pos[0] = cx + o_signf(dx) * r->riverChannelWidth;
+                if (dx * q->vel[0] > 0.0f) q->vel[0] = 0.0f;
+            }
+        }
+        /* ---- StreamEmit.comp:31-60 ---- */
+        if (q->pos[1] < r->riverSinkY || q->pos[2] > r->riverSinkZMax) {
+            uint32_t s = (uint32_t)i * 1664525u + 1013904223u;
+            const float r1 = (float)(s & 0xFFFFu) / 65535.0f;
+            s = s * 1664525u + 1013904223u;                                 /* r2 is drawn and unused, :40-41 */
+            s = s * 1664525u + 1013904223u;
+            const float r3 = (float)(s & 0xFFFFu) / 65535.0f;
+            s = s * 1664525u + 1013904223u;
+            const float r4 = (float)(s & 0xFFFFu) / 65535.0f;
+            const float spawnZ = r->riverEmitterPos[2] + r1 * spreadZ;
+            const float cx = p->boxCenter[0] + r->riverAmp * sph_oracle_sinf(r->riverFreq * spawnZ + r->riverPhase);
+            q->pos[0] = cx + (r4 - 0.5f) * 2.0f * r->riverEmitterRadius;
+            q->pos[1] = r->riverEmitterPos[1] + r3 * 0.6f;
+            q->pos[2] = spawnZ;
+            q->vel[0] = r->riverEmitterVel[0]; q->vel[1] = r->riverEmitterVel[1]; q->vel[2] = r->riverEmitterVel[2]; q->vel[3] = 0.0f;
+            q->acc[0] = q->acc[1] = q->acc[2] = q->acc[3] = 0.0f;
+            q->density = p->restDensity;
+            q->pressure = 0.0f;
+        }
+    }
+}
+
+/* DispatchCompute in river mode (:431-522): the substep, then step 5; the fountain step does not run (:519). */
+void sph_oracle_substep_river(OParticle* P, OParticle* scratch, int n, const OParams* p, float overrideDt, const ORiver* r, const float* T) {
+    if (p->pause) return;
+    sph_oracle_substep(P, scratch, n, p, overrideDt);
+    if (r && r->riverMode && T) sph_oracle_river(P, n, p, r, T);
+}
