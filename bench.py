@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--workload", default="auto", help="auto (config3 at N = 1, weak5 at N > 1) | config2 | config3 | weak5 (BASELINE configs[4] slab)")
     ap.add_argument("--settled-after", type=int, default=300, help="N = 1: after the timed run, continue the SAME run to this substep and record the settled regime (0 = skip)")
     ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 = k_sph_list (engine default), 1 = k_sph_slow (plain per-target sweeps)")
-    ap.add_argument("--aos", default="eager", choices=["eager", "lazy"])
+    ap.add_argument("--aos", default="lazy", choices=["eager", "lazy"], help="lazy (engine default): the 80-byte records are materialised once per frame; eager: by every substep")
+    ap.add_argument("--frame-substeps", type=int, default=16, help="lazy, N = 1: materialise the 80-byte record array (sph_device_particles, what a renderer binds) after every this many "
+                    "substeps INSIDE the timed region (Scene0p.h:48 maxSubstepsPerFrame = 16) and once more at its end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="substeps of the CPU sample (0 = auto, about 10-30 s)")
     ap.add_argument("--grid-build", default="sort", choices=["sort", "ll"], help="counting sort (default) or the reference's linked lists (A/B)")
@@ -151,23 +153,39 @@ def main():
     wave_every = 16 if wl == "weak5" else 0
     wave = {"n": 0, "phase": 0.0}
 
+    # lazy records, one GPU: the renderer's view (the 80-byte array in original order) is brought up to date once per
+    # frame, as Scene0p binds it once per frame after up to 16 substeps (Scene0p.cpp:1482-1494, :1625); that work is part
+    # of the timed region.  z-slab runs never held a fused record array (owned records are gathered by download_owned()).
+    frame = args.frame_substeps if (args.gpus == 1 and args.aos == "lazy") else 0
+    materialised = {"n": 0}
+
+    def present():
+        sim.device_particles()
+        materialised["n"] += 1
+
     def step():
         if wave_every and wave["n"] % wave_every == 0:
             sim.ApplyWaveImpulse(1.5, 3.0, wave["phase"], (0.0, 1.0, 0.0))
             wave["phase"] += 4.0 * 16 * 1e-3
         wave["n"] += 1
         sim.DispatchCompute(dt)
+        if frame and wave["n"] % frame == 0:
+            present()
 
     for _ in range(args.warmup):
         step()
     sim.set_option(pkg.SPH_OPT_TIMING, 2)          # hipEvents around the dominant kernel only
     sim.kernel_times(reset=True)
     barrier()
+    materialised["n"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if args.gpus == 1 and args.aos == "lazy":
+        present()                                  # the timed region ends with a current record array
     barrier()
     elapsed = time.perf_counter() - t0
+    records_materialised = materialised["n"]
     kt = sim.kernel_times(reset=True)
     sim.set_option(pkg.SPH_OPT_TIMING, 0)
     if dist is not None:
@@ -222,6 +240,28 @@ def main():
         settled = {"after_substeps": max(args.settled_after, done), "substeps_timed": ns, "sph_pass_us": round(sms / max(scnt, 1) * 1e3, 1),
                    "ms_per_step": round(tse / ns * 1e3, 3), "particle_substeps_per_s": n_total * ns / tse}
 
+    # For the record (untimed for `value`): the same workload and window on a fresh engine with the records updated
+    # by every substep (SPH_OPT_AOS_MODE 0), i.e. what the fused scattered record update costs.
+    aos_eager = None
+    if args.gpus == 1 and args.aos == "lazy" and not args.no_breakdown and args.grid_build == "sort":
+        sim2 = pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream)
+        sim2.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
+        sim2.set_option(pkg.SPH_OPT_AOS_MODE, 0)
+        for _ in range(args.warmup):
+            sim2.DispatchCompute(dt)
+        sim2.set_option(pkg.SPH_OPT_TIMING, 2)
+        sim2.kernel_times(reset=True)
+        barrier()
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            sim2.DispatchCompute(dt)
+        barrier()
+        te = time.perf_counter() - te
+        ems, ecnt = sim2.kernel_times(reset=True)["sph"]
+        sim2.close()
+        aos_eager = {"value": n_total * args.steps / te, "ms_per_step": round(te / args.steps * 1e3, 4), "sph_pass_us": round(ems / max(ecnt, 1) * 1e3, 1),
+                     "note": "same workload, warm-up and window with SPH_OPT_AOS_MODE 0 (the SPH pass also updates every 80-byte record), fresh engine, not the headline"}
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -263,8 +303,12 @@ def main():
                         + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")"
                         + ("" if backend == "nccl" else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]"),
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
-            "neighbor_kernel": (None, "k_sph_slow", "k_sph_list")[args.neighbor], "aos": args.aos,
-            "pipeline": ("bin+scan+scatter+rank -> sph(27-cell, OBB + AoS update fused)" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB + AoS update fused)") + (" + halo exchange" if args.gpus > 1 else ""),
+            "neighbor_kernel": (None, "k_sph_slow", "k_sph_list")[args.neighbor],
+            "aos": (args.aos if args.gpus > 1 or args.aos == "eager" else
+                    f"lazy: 80-byte records materialised (sph_device_particles) every {frame} substeps and at the end, inside the timed region: {records_materialised} times in {args.steps} substeps"),
+            "pipeline": (("bin+scan+scatter+rank -> sph(27-cell, OBB fused" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB fused")
+                         + (", AoS update fused)" if (args.aos == "eager" and args.gpus == 1) else ") -> record write-back once per frame" if args.gpus == 1 else ")"))
+                        + (" + halo exchange" if args.gpus > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -275,6 +319,7 @@ def main():
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },
         "kernels_us_per_substep": breakdown,
+        "aos_eager": aos_eager,
         "settled": settled,
         "valu": valu,
     }

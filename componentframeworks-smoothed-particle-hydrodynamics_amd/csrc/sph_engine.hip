@@ -69,7 +69,7 @@ struct SphEngine {
     uint32_t idBase = 0;
 
     // options
-    int optNeighbor = 2, optGridBuild = 0, optAos = 0, optTiming = 0, optGraph = 0;
+    int optNeighbor = 2, optGridBuild = 0, optAos = 1, optTiming = 0, optGraph = 0;   // optAos: 1 = records materialised on demand (default)
     // hipGraph cache of sph_dispatch_n (SPH_OPT_GRAPH): one executable graph per distinct call
     struct GraphEntry {
         uint64_t key = 0;
@@ -117,7 +117,9 @@ struct SphEngine {
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
     float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
     sph::ShapeTab shapeTab{};
-    uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count
+    bool slabOrderValid = false;            // slots are in the order of the last counting sort and no particle can have moved by more than a layer since
+    float lastContainer[15] = {0};          // container / grid members of the last dispatch (a change may move particles by many cells, or the grid under them)
+    uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count, [4] flags, [5] / [6] counts of the last async pack
     int debugFlags = 0;
     unsigned long long* d_stats = nullptr;   // k_sph_list diagnostics (SPH_OPT_DEBUG bit 3), see sph_debug_counters
 
@@ -134,6 +136,20 @@ struct SphEngine {
 namespace {
 
 using namespace sph;
+
+// Members that decide where the container walls and the grid are (for the slab exchange's reduced scan).
+void container_key(const SphParams& q, float out[15]) {
+    const float v[15] = {q.param_boxCenter[0], q.param_boxCenter[1], q.param_boxCenter[2], q.param_boxHalf[0], q.param_boxHalf[1], q.param_boxHalf[2],
+                         q.param_boxEulerDeg[0], q.param_boxEulerDeg[1], q.param_boxEulerDeg[2], (float)q.param_shapeType,
+                         q.param_shapeAux[0], q.param_shapeAux[1], q.param_shapeAux[2], q.param_h, (float)q.grid_cap};
+    std::memcpy(out, v, sizeof(v));
+}
+bool slab_ranges_usable(const SphEngine* e) {
+    if (!e->slabOrderValid) return false;
+    float cont[15];
+    container_key(e->params, cont);
+    return std::memcmp(cont, e->lastContainer, sizeof(cont)) == 0;   // same walls and same grid as the dispatch that sorted the slots
+}
 
 int flush_events(SphEngine* e) {
     if (e->evLive.empty()) return SPH_OK;
@@ -271,7 +287,8 @@ int import_state(SphEngine* e) {
 
 // ClearGrid + BuildGrid as a counting sort: after this, d_cellStart/d_order describe the
 // current state buffer.
-int build_grid(SphEngine* e, const SimK& k) {
+// commitLive (z-slab dispatch only): k_rank also stores the live count as the new slots-in-use count of the exchange.
+int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     const int n = (int)(e->slab ? e->nSlots : e->n), C = k.numCells;
     const int nb = blocks_for(n), sb = blocks_for((size_t)C, kScanTile);
     const bool sortedCopy = e->optGridBuild == 0;     // k_rank also writes the sorted copy the SPH pass reads
@@ -299,10 +316,12 @@ int build_grid(SphEngine* e, const SimK& k) {
                            e->slab ? e->d_slabCnt + 2 : (const uint32_t*)nullptr);
         if (sortedCopy) {
             hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn, k.gx, k.gy);
+                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn, k.gx, k.gy,
+                               (commitLive && e->slab) ? e->d_slabCnt + 2 : (uint32_t*)nullptr);
         } else {
             hipLaunchKernelGGL((k_rank<false>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.gx, k.gy);
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.gx, k.gy,
+                               (commitLive && e->slab) ? e->d_slabCnt + 2 : (uint32_t*)nullptr);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -387,7 +406,7 @@ int dispatch_one(SphEngine* e, float overrideDt) {
             hipLaunchKernelGGL(k_sph_ll, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, cellHead, e->d_llNext, n);
         }
     } else {
-    if ((rc = build_grid(e, k))) return rc;                                 // :449-468
+    if ((rc = build_grid(e, k, true))) return rc;                           // :449-468
     if (n) {                                                                // :470-509 (SPH + OBB fused)
         if (!e->d_sPos || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
         const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
@@ -444,8 +463,16 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     e->cur = nx;
     e->accValid = !fuseAos;
     e->aosValid = fuseAos;
-    if (e->slab) {   // the sorted output holds exactly the live particles: remember their count on the device
-        HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, e->d_cellStart + k.numCells, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+    if (e->slab) {   // the sorted output holds exactly the live particles: their count is on the device (slabCnt[2])
+        const bool sorted = e->optGridBuild != 1 && n > 0;
+        if (!sorted) HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, e->d_cellStart + k.numCells, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));   // (k_rank stored it otherwise)
+        // the next k_slab_pack may restrict itself to the ends of the slot range if this substep cannot have moved a
+        // particle by more than one layer: velocity cap (always), and a container that did not change under the fluid
+        float cont[15];
+        container_key(e->params, cont);
+        const bool sameContainer = std::memcmp(cont, e->lastContainer, sizeof(cont)) == 0;
+        std::memcpy(e->lastContainer, cont, sizeof(cont));
+        e->slabOrderValid = sorted && sameContainer;
         return SPH_OK;
     }
     if (e->optAos == 0 && !e->aosValid) return writeback(e);
@@ -648,7 +675,8 @@ static std::vector<unsigned char> graph_material(const SphEngine* e, float dt, i
     auto add = [&](const void* p, size_t len) { const unsigned char* b = static_cast<const unsigned char*>(p); m.insert(m.end(), b, b + len); };
     add(&e->params, sizeof(e->params));
     add(&dt, sizeof(dt)); add(&n, sizeof(n));
-    const int opts[8] = {e->optNeighbor, e->optGridBuild, e->optAos, e->cur, (e->aosValid ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0),
+    // (whether the 80-byte array is current on entry only shapes the launches of the eager mode: fused update or write-back)
+    const int opts[8] = {e->optNeighbor, e->optGridBuild, e->optAos, e->cur, ((e->aosValid && e->optAos == 0) ? 1 : 0) | (e->accValid ? 2 : 0) | (e->internalValid ? 4 : 0),
                          (int)e->idBase, e->allocatedCells, 0};
     add(opts, sizeof(opts));
     const void* ptrs[20] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_vel[0], e->d_vel[1], e->d_rp[0], e->d_rp[1], e->d_foam[0], e->d_foam[1], e->d_acc,
@@ -1014,6 +1042,7 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
     SimK k;
     make_simk(e->params, e->grid, e->params.param_timeStep, k);
     HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 2 * sizeof(uint32_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_slabCnt + 5, 0, 2 * sizeof(uint32_t), e->stream));      // counts of an earlier async pack
     uint32_t host[3] = {0, 0, 0};
     // e->nSlots bounds the slots in use; the device-side live count (slabCnt[2]) trims it to the
     // slots that hold data, so no host round trip is needed before the launch
@@ -1021,7 +1050,8 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
         Timed t(e, SPH_K_OTHER);
         hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->nSlots)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
                            e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], (int)e->nSlots,
-                           (SlabRec*)sendLo, (SlabRec*)sendHi, capLo, capHi, e->d_slabCnt);
+                           (SlabRec*)sendLo, (SlabRec*)sendHi, capLo, capHi, e->d_slabCnt,
+                           slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -1105,12 +1135,12 @@ int sph_slab_pack_async(SphEngine* e) {
     SimK k;
     make_simk(e->params, e->grid, e->params.param_timeStep, k);
     e->nSlots = e->cap;                                     // from now on only a launch bound: slabCnt[2] counts the slots in use
-    HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 2 * sizeof(uint32_t), e->stream));
-    {
+    {                                                       // (slabCnt[0..1] are zero: set at creation, reset by k_slab_headers)
         Timed t(e, SPH_K_OTHER);
         hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->cap)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
                            e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], (int)e->cap,
-                           e->d_face[0] + 1, e->d_face[1] + 1, e->faceCap, e->faceCap, e->d_slabCnt);
+                           e->d_face[0] + 1, e->d_face[1] + 1, e->faceCap, e->faceCap, e->d_slabCnt,
+                           slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
         hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, e->hasLo ? e->d_face[0] : (SlabRec*)nullptr,
                            e->hasHi ? e->d_face[1] : (SlabRec*)nullptr, e->faceCap, e->faceCap);
     }
@@ -1141,7 +1171,8 @@ int sph_slab_status(SphEngine* e, uint32_t out[5]) {
     HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, sizeof(host), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < 5; ++i) out[i] = host[i];
-    if (host[4] & 1u) return fail(SPH_ERR_CAPACITY, "halo send buffer overflowed (%u / %u records for a capacity of %u)", host[0], host[1], e->faceCap);
+    out[0] += host[5]; out[1] += host[6];                   // the async pack keeps its counts there (k_slab_headers resets [0], [1])
+    if (host[4] & 1u) return fail(SPH_ERR_CAPACITY, "halo send buffer overflowed (%u / %u records for a capacity of %u)", out[0], out[1], e->faceCap);
     if (host[4] & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
     return SPH_OK;
 }

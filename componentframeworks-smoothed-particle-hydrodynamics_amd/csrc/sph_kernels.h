@@ -199,8 +199,12 @@ __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, 
                                                  const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells,
                                                  const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                  const float2* __restrict__ rp, const float* __restrict__ foam,
-                                                 float4* __restrict__ posI, float4* __restrict__ velP, float4* __restrict__ own, int gx, int gy) {
+                                                 float4* __restrict__ posI, float4* __restrict__ velP, float4* __restrict__ own, int gx, int gy,
+                                                 uint32_t* __restrict__ liveOut) {
     int d = blockIdx.x * kBlock + threadIdx.x;
+    // z-slab mode: the sorted output will hold exactly the live particles; their count replaces the slots-in-use count
+    // of the exchange (k_bin / k_scatter, which read that count, have finished)
+    if (d == 0 && liveOut) *liveOut = cellStart[numCells];
     if (d >= n || (uint32_t)d >= cellStart[numCells]) return;   // live particles only (cellStart[numCells] <= n)
     uint2 me = tmp[d];
     uint32_t c = cellOf[me.y];
@@ -748,10 +752,20 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
                                                       const float4* __restrict__ vel, const float2* __restrict__ rp,
                                                       const float* __restrict__ foam, int nBound, SlabRec* __restrict__ sendLo,
                                                       SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi,
-                                                      uint32_t* __restrict__ counters) {
+                                                      uint32_t* __restrict__ counters, const uint32_t* __restrict__ cellStart, int layerCells) {
+    const int gzLocal = z1 - z0 + 2;                    // the rank's layers plus one ghost layer each side (k holds the GLOBAL grid here)
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int n = min(nBound, (int)counters[2]);       // counters[2] = slots that hold data (live count of the last sort)
     if ((int)(blockIdx.x * kBlock) >= n) return;       // whole block beyond the data
+    // cellStart != nullptr: the slots are still in the order of the last counting sort (z-major) and nothing moved a
+    // particle by more than one cell layer since (velocity cap, unchanged container).  Everything this pass acts on --
+    // stale ghosts, face particles, migrants -- then entered that substep in one of the three lowest or three highest
+    // local layers, i.e. sits in two slot ranges at the ends; blocks in between have nothing to do.
+    if (cellStart && gzLocal > 6) {
+        const int endLo = (int)cellStart[3 * layerCells], startHi = (int)cellStart[(gzLocal - 3) * layerCells];
+        const int b0 = (int)(blockIdx.x * kBlock);
+        if (b0 >= endLo && b0 + kBlock <= startHi) return;
+    }
     bool toLoBuf = false, toHiBuf = false;
     SlabRec r;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = r.rho = r.prs = r.foam = 0.0f; r.id = 0; r.flags = 0; r.pad = 0;
@@ -807,6 +821,8 @@ __global__ void k_slab_headers(uint32_t* __restrict__ counters, SlabRec* __restr
     if (nl > capLo || nh > capHi) atomicOr(&counters[4], 1u);
     if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nl, capLo); h.flags = 0x48414c4fu; h.pad = nl; sendLo[0] = h; }
     if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nh, capHi); h.flags = 0x48414c4fu; h.pad = nh; sendHi[0] = h; }
+    counters[5] = nl; counters[6] = nh;                 // what sph_slab_status reports
+    counters[0] = 0u; counters[1] = 0u;                 // ready for the next k_slab_pack (no memset between substeps)
 }
 // recv[0] is the header (id = record count), recv[1..] the payload; appended behind slot counters[2] (+ the other
 // direction's count when `afterOther` points at that header).

@@ -136,7 +136,9 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
     // leave the last XCDs without work)
     const int nBlocks = (bound + kB - 1) / kB, perXcd = (nBlocks + 7) >> 3;
     const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
-    if (vb >= nBlocks) return;                               // whole block, uniformly
+    // (a z-slab launch covers the slot CAPACITY: blocks past the 8 x perXcd that map one-to-one onto the live slots leave,
+    // otherwise they would compute some virtual block a second time)
+    if (((int)blockIdx.x >> 3) >= perXcd || vb >= nBlocks) return;   // whole block, uniformly
     const int sRaw = vb * kB + tid;
     bool live = sRaw < bound;                                // every lane stays to the end (the staging is a wave-wide cooperation)
     const int s = live ? sRaw : max(bound - 1, 0);
@@ -195,16 +197,23 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
         nl[min(cnt, MAXN)][tid] = (uint16_t)e;
         cnt += p;
     };
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const uint32_t q0 = qs[r], q1 = qe[r];
+    // The wave-uniform facts of a row (who has candidates, the union [A, B) of the lanes' runs, whether it fits the LDS
+    // window) and the window's loads are formed ONE ROW AHEAD: the loads of row r + 1 are in flight while row r is walked
+    // out of LDS (the staged walk issues no global loads, so nothing waits on them before the next row's LDS store).
+    static_assert(CAP <= 128, "the window is staged with two loads per lane");
+    unsigned long long mneN = 0ull;
+    uint32_t aN = 0u, bN = 0u;
+    bool stagedN = false;
+    float4 pre0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre1 = pre0;
+    auto plan = [&](uint32_t q0, uint32_t q1) {
         // union of the wave's ranges of this row: lanes are consecutive sorted slots, so the row bases ascend with the
         // lane and the union runs from the first non-empty lane's start to the last one's end (two readlanes; checked,
         // with wave reductions as the fallback)
         const bool ne = q1 > q0;
-        const unsigned long long mne = __ballot(ne);
-        if (mne == 0ull) continue;                         // nobody has a candidate in this row
-        const int lf = __ffsll((long long)mne) - 1, ll = 63 - __clzll((long long)mne);
+        mneN = __ballot(ne);
+        aN = bN = 0u; stagedN = false;
+        if (mneN == 0ull) return;                          // nobody has a candidate in this row
+        const int lf = __ffsll((long long)mneN) - 1, ll = 63 - __clzll((long long)mneN);
         uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
         uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
         if (__any(ne && (q0 < A || q1 > B))) {             // not ascending (cannot happen for consecutive slots; kept exact anyway)
@@ -212,14 +221,33 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
             for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); }
             A = lo; B = hi;
         }
+        aN = A; bN = B;
+        stagedN = (B - A) <= (uint32_t)CAP && !(dbg & 4);  // wave-uniform
+        if (stagedN) {                                     // clamped, unconditional: B - A >= 1 here
+            pre0 = S.posI[A + min((uint32_t)lane, B - A - 1u)];
+            if (CAP > 64) pre1 = S.posI[A + min((uint32_t)lane + 64u, B - A - 1u)];
+        }
+    };
+    plan(qs[0], qe[0]);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t q0 = qs[r], q1 = qe[r];
+        const bool ne = q1 > q0;
+        const unsigned long long mne = mneN;
+        const uint32_t A = aN, B = bN;
+        const bool staged = stagedN;
+        if (mne != 0ull && staged) {                       // this row's window into LDS (lanes past the union store duplicates)
+            stage[wv][lane] = pre0;
+            if (CAP > 64 && lane < CAP - 64) stage[wv][lane + 64] = pre1;
+        }
+        if (r < 8) plan(qs[r + 1], qe[r + 1]);
+        if (mne == 0ull) continue;
         if (lane == 0) rowA[wv][r] = A;
         if (B - A > 4095u) listOk = false;                 // offsets beyond the entry format (wave-uniform)
-        const bool staged = (B - A) <= (uint32_t)CAP && !(dbg & 4);   // wave-uniform
         const uint32_t len = q1 - q0;
         const uint32_t ebase = ((uint32_t)r << 12) | ((ne ? q0 - A : 0u) & 0xfffu);
         uint32_t m = 0;
         if (staged) {
-            for (uint32_t i = (uint32_t)lane; i < B - A; i += 64u) stage[wv][i] = S.posI[A + i];
             __builtin_amdgcn_wave_barrier();
             const float4* __restrict__ wp = &stage[wv][ne ? q0 - A : 0u];
             for (; m + UNROLL <= len; m += UNROLL) {       // full groups: no validity tests, immediate LDS offsets

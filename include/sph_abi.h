@@ -124,7 +124,7 @@ typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHF
 enum {
     SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = k_sph_list (default: one target per lane, LDS-staged candidate rows, neighbour lists), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
-    SPH_OPT_AOS_MODE = 3,        /* 0 = eager: the 80-byte array is current after every dispatch (default); 1 = lazy: materialised by sph_device_particles()/download */
+    SPH_OPT_AOS_MODE = 3,        /* 1 = lazy (default): the substep keeps its state in the engine's own arrays and the 80-byte records are brought up to date by sph_device_particles() / sph_download_particles() / sph_pack_render_buffer(), i.e. once per rendered frame instead of once per substep (the scattered 52-byte update of every record costs about 13 % of the SPH pass); 0 = eager: the SPH pass also updates the records, they are current after every dispatch. Same values either way. */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
     SPH_OPT_GRAPH_LAUNCHES = 6,  /* read-only: number of graph replays so far */
     SPH_OPT_TIMING = 4,          /* hipEvents around kernels for sph_kernel_times(): 1 = every kernel, 2 = only the SPH pass */

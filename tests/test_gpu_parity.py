@@ -414,6 +414,32 @@ def test_dispatch_n_graph_replay(pkg, oracle):
     f.close()
 
 
+def test_records_are_materialised_on_demand_by_default(pkg, oracle):
+    """SPH_OPT_AOS_MODE defaults to 1: substeps keep their state in the engine's arrays, and every reader of the 80-byte
+    records (download, device pointer, render pack) brings them up to date first -- once per frame in a scene, not once
+    per substep.  Same bits as the eager mode, whichever reader comes first and however the two modes alternate."""
+    import torch
+    rec, sp = small_scene(pkg, n=5000, grid=16, seed=77)
+    op = to_oracle_params(oracle, sp)
+    f = pkg.SPHFluidGPU.from_particles(rec, sp)
+    assert f.get_option(pkg.SPH_OPT_AOS_MODE) == 1
+    f.DispatchN(16)                                                  # one frame
+    want = oracle.substep(rec, op, steps=16)
+    buf = torch.zeros((len(rec), 4), dtype=torch.float32, device="cuda")
+    f.pack_render_buffer(buf.data_ptr(), 1)                          # first reader: the render pack
+    f.sync()
+    got = buf.cpu().numpy()
+    assert got[:, :3].tobytes() == want["pos"][:, :3].tobytes() and got[:, 3].tobytes() == want["density"].tobytes()
+    assert f.device_particles() != 0
+    assert_records_equal(f.download(), want, "lazy records after one frame")
+    f.set_option(pkg.SPH_OPT_AOS_MODE, 0)                            # eager from here: the pass updates the records itself
+    f.DispatchN(3)
+    f.set_option(pkg.SPH_OPT_AOS_MODE, 1)
+    f.DispatchN(2)
+    assert_records_equal(f.download(), oracle.substep(want, op, steps=5), "eager and lazy substeps mixed")
+    f.close()
+
+
 def test_unreasonable_members_are_refused_not_faulted(pkg):
     """Members a UI slider or a preset could produce must end in an error message, never in a device
     fault: a grid beyond 2^30 cells (huge box with a raised grid_cap), a non-positive h, NaN extents."""

@@ -98,6 +98,38 @@ def test_async_exchange_matches_single_engine(pkg, oracle, world):
     single.close()
 
 
+def test_container_change_under_the_reduced_face_scan(pkg, oracle):
+    """k_slab_pack looks only at the two ends of the (z-major sorted) slot range while nothing can have moved a particle
+    by more than one layer.  A container that changes under the fluid can: box -> sphere of the same extent (same grid)
+    projects the corner particles many cells inwards, across slab boundaries.  The substep after such a change must
+    scan every slot again; the result stays the single engine's, bit for bit."""
+    import torch
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, 3)
+    grp.enable_async(8192)
+    single = pkg.SPHFluidGPU.from_particles(P, sp)
+    want = P
+    for s in range(9):
+        if s == 4:
+            sp.param_shapeType = 1                    # the slab engines share `sp`; the single engine has its own copy
+            single.param_shapeType = 1
+            op.shapeType = 1
+        torch.cuda.synchronize()
+        grp.DispatchCompute()
+        single.DispatchCompute()
+        want = oracle.substep(want, op)
+    assert pkg.compute_grid_extents(sp).numCells == pkg.compute_grid_extents(single.params).numCells
+    got = halo.merge_into_records(P, grp.download())
+    moved = np.linalg.norm(got["pos"][:, :3] - P["pos"][:, :3], axis=1)
+    assert moved.max() > 2.0 * sp.param_h             # some particles did jump several cells
+    assert_records_equal(got, single.download(), "3 slabs vs one engine across a container change")
+    assert_records_equal(got, want, "3 slabs vs oracle across a container change")
+    st = [x.engine.status() for x in grp.sims]
+    assert all(x[4] == 0 for x in st)
+    single.close()
+
+
 def test_async_exchange_reports_overflow(pkg, oracle):
     halo = importlib.import_module(PKG_NAME + ".halo")
     P, sp, op = _scene(pkg, oracle)
