@@ -206,21 +206,17 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
     bool stagedN = false;
     float4 pre0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre1 = pre0;
     auto plan = [&](uint32_t q0, uint32_t q1) {
-        // union of the wave's ranges of this row: lanes are consecutive sorted slots, so the row bases ascend with the
-        // lane and the union runs from the first non-empty lane's start to the last one's end (two readlanes; checked,
-        // with wave reductions as the fallback)
+        // union of the wave's ranges of this row: the lanes are consecutive sorted slots, so their cells ascend with the
+        // lane; the neighbour cell (x - 1 clamped, y + dy, z + dz) and with it cellStart[...] ascends too (the clamp at
+        // x = 0 keeps the order, rows outside the grid are empty and excluded).  The union therefore runs from the first
+        // non-empty lane's start to the last one's end: two readlanes.
         const bool ne = q1 > q0;
         mneN = __ballot(ne);
         aN = bN = 0u; stagedN = false;
         if (mneN == 0ull) return;                          // nobody has a candidate in this row
         const int lf = __ffsll((long long)mneN) - 1, ll = 63 - __clzll((long long)mneN);
-        uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
-        uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
-        if (__any(ne && (q0 < A || q1 > B))) {             // not ascending (cannot happen for consecutive slots; kept exact anyway)
-            uint32_t lo = ne ? q0 : 0xffffffffu, hi = ne ? q1 : 0u;
-            for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); }
-            A = lo; B = hi;
-        }
+        const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)q0, lf);
+        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
         aN = A; bN = B;
         stagedN = (B - A) <= (uint32_t)CAP && !(dbg & 4);  // wave-uniform
         if (stagedN) {                                     // clamped, unconditional: B - A >= 1 here

@@ -419,7 +419,7 @@ def test_records_are_materialised_on_demand_by_default(pkg, oracle):
     records (download, device pointer, render pack) brings them up to date first -- once per frame in a scene, not once
     per substep.  Same bits as the eager mode, whichever reader comes first and however the two modes alternate."""
     import torch
-    rec, sp = small_scene(pkg, n=5000, grid=16, seed=77)
+    rec, sp = small_scene(pkg, n=4000, grid=16, seed=77)
     op = to_oracle_params(oracle, sp)
     f = pkg.SPHFluidGPU.from_particles(rec, sp)
     assert f.get_option(pkg.SPH_OPT_AOS_MODE) == 1
