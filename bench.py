@@ -262,6 +262,23 @@ def main():
         aos_eager = {"value": n_total * args.steps / te, "ms_per_step": round(te / args.steps * 1e3, 4), "sph_pass_us": round(ems / max(ecnt, 1) * 1e3, 1),
                      "note": "same workload, warm-up and window with SPH_OPT_AOS_MODE 0 (the SPH pass also updates every 80-byte record), fresh engine, not the headline"}
 
+    # z-slab runs: overflow of a face buffer or of the slot capacity is flagged on the device, never fatal in the
+    # substep loop; a run that dropped records is not a measurement, so every rank's flags go into the line.
+    slab_status = None
+    if args.gpus > 1:
+        try:
+            st = sim.engine.status()
+            mine = [int(st[0]), int(st[1]), int(st[2]), 0]
+        except Exception as ex:                          # noqa: BLE001  (SphError: the status call reports an overflow as an error)
+            mine = [0, 0, 0, 1]
+            print(f"[rank {rank}] slab status: {ex}", file=sys.stderr, flush=True)
+        tst = torch.tensor(mine, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(tst) for _ in range(world)]
+        dist.all_gather(gathered, tst)
+        slab_status = {"records_lo_hi_live_per_rank": [[int(v) for v in g[:3].tolist()] for g in gathered],
+                       "overflow_on_any_rank": bool(sum(int(g[3].item()) for g in gathered)),
+                       "face_capacity_records": int(sim.engine.face_cap) if hasattr(sim.engine, "face_cap") else None}
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -319,6 +336,7 @@ def main():
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },
         "kernels_us_per_substep": breakdown,
+        "slab_status": slab_status,
         "aos_eager": aos_eager,
         "settled": settled,
         "valu": valu,

@@ -107,6 +107,7 @@ struct SphEngine {
     size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count (= cap once the async exchange is used)
     sph::SlabRec* d_face[4] = {nullptr, nullptr, nullptr, nullptr};   // engine-owned halo buffers: send lo / hi, recv lo / hi ((faceCap + 1) records, record 0 = header)
     uint32_t faceCap = 0;
+    const void* faceAgreedWith = nullptr;   // communicator whose ranks were checked to share faceCap (sph_slab_exchange)
     SphFountain fountain{};                 // fountain* members (SPHFluid3D.h:161-168)
     SphRiver river{};                       // river / terrain members (SPHFluid3D.h:171-196)
     std::vector<float> terrainHeights;      // CPU copy of the heightfield (:175); empty = river step off (:512)
@@ -1120,6 +1121,7 @@ int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap) {
         HIP_TRY(hipMemsetAsync(e->d_face[i], 0, sizeof(SlabRec), e->stream));      // empty header
     }
     e->faceCap = faceCap;
+    e->faceAgreedWith = nullptr;
     return SPH_OK;
 }
 int sph_slab_face_buffer(SphEngine* e, int which, void** devPtr) {
@@ -1191,6 +1193,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -1208,10 +1211,11 @@ int rccl_load() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
     r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
     r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
         dlclose(h);
         return fail(SPH_ERR_HIP, "RCCL library lacks a required entry point");
     }
@@ -1270,6 +1274,26 @@ int sph_slab_exchange(SphEngine* e, SphComm* c) {
     if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
     if ((e->hasLo && c->rank == 0) || (e->hasHi && c->rank == c->world - 1)) return fail(SPH_ERR_ARG, "slab neighbours do not match rank %d of %d", c->rank, c->world);
     int rc;
+    if (e->faceAgreedWith != c) {
+        // Once per (engine, communicator): the face capacity is the size of every message, so all ranks must have
+        // allocated the same one -- a mismatch would otherwise show up as a hang inside ncclSend / ncclRecv.
+        uint32_t* d = nullptr;
+        if ((rc = dev_alloc(&d, 2))) return rc;
+        const uint32_t mine[2] = {e->faceCap, ~e->faceCap};
+        uint32_t agreed[2] = {0, 0};
+        hipError_t er = hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, e->stream);
+        ncclResult_t nr = ncclSuccess;
+        if (er == hipSuccess) nr = g_rccl.AllReduce(d, d, 2, ncclUint32, ncclMax, c->comm, e->stream);
+        if (er == hipSuccess && nr == ncclSuccess) er = hipMemcpyAsync(agreed, d, sizeof(agreed), hipMemcpyDeviceToHost, e->stream);
+        if (er == hipSuccess && nr == ncclSuccess) er = hipStreamSynchronize(e->stream);
+        (void)hipFree(d);
+        if (nr != ncclSuccess) return fail(SPH_ERR_HIP, "ncclAllReduce failed: %s", g_rccl.GetErrorString(nr));
+        if (er != hipSuccess) return fail(SPH_ERR_HIP, "face capacity agreement failed: %s", hipGetErrorString(er));
+        if (agreed[0] != e->faceCap || agreed[1] != ~e->faceCap)
+            return fail(SPH_ERR_ARG, "face capacity %u differs between ranks (largest %u, smallest %u): sph_slab_alloc_faces must be given the same value everywhere",
+                        e->faceCap, agreed[0], ~agreed[1]);
+        e->faceAgreedWith = c;
+    }
     if ((rc = sph_slab_pack_async(e))) return rc;
     const size_t bytes = ((size_t)e->faceCap + 1) * sizeof(SlabRec);
     if (e->hasLo || e->hasHi) {

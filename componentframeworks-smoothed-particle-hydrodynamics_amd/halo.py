@@ -78,6 +78,7 @@ class HipSlabEngine:
     def alloc_faces(self, face_cap: int):
         _eng._check(self._L.sph_slab_alloc_faces(self._h, int(face_cap)))
         self.face_cap = int(face_cap)
+        self.face_cap = int(face_cap)
 
     def face_ptr(self, which: int) -> int:
         p = C.c_void_p()
@@ -247,17 +248,27 @@ class SlabSimulation:
 
     # -- construction from a synthetic config (bench.py) ---------------------------------------
     @classmethod
-    def from_config(cls, cfg, params, rank, world, stream=None, group=None, transport="direct"):
+    def from_config(cls, cfg, params, rank, world, stream=None, group=None, transport="direct", face_factor=1.6, slot_factor=1.5):
         import torch
         gx, gy, gz = cfg.grid
         z0, z1 = slab_range(gz, rank, world)
         rec, gid = _syn.make_particles(cfg, z_cells=(z0, z1))
-        # a face carries one boundary layer of copies plus the migrants; slots: owned + two ghost layers + arrivals.
-        # Kept tight on purpose: kernels are launched over the slot CAPACITY in the exchange without host round trips,
-        # and blocks launched for empty slots cost time (tools/slab_overhead_detail.py)
-        per_layer = max(1, len(rec) // max(1, z1 - z0))
-        face_cap = int(per_layer * 2.5 + 4096)
-        cap = int(len(rec) * 1.06 + 2 * face_cap)
+        # a face carries one boundary layer of copies plus the migrants (face_factor cell layers' worth of the average
+        # layer); slots: slot_factor x the owned particles (a collapsing column moves particles into the lower slabs)
+        # + two faces.  Spare slots cost almost nothing: blocks past the live count leave at once.
+        # The face capacity is the MESSAGE SIZE of sph_slab_exchange (fixed-size buffers, the count travels in record 0):
+        # it must be the same number on both ends of a link, so it is derived from the global configuration, never from
+        # this rank's own particle count (ranks hold 82 or 83 lattice planes of the same column), and agreed on by an
+        # all-reduce when a process group exists.
+        per_layer = max(1, -(-cfg.n // max(1, gz)))
+        face_cap = int(per_layer * face_factor + 8192)
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                t = torch.tensor([face_cap], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                face_cap = int(t.item())
+        cap = int(len(rec) * slot_factor + 2 * face_cap)
         eng = HipSlabEngine(rec, gid.astype(np.uint32), params, z0, z1, rank > 0, rank < world - 1, cap, stream=stream)
         dev = torch.device("cuda", torch.cuda.current_device())
         if transport == "rccl":

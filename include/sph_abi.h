@@ -273,8 +273,10 @@ int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nO
  * sph_slab_exchange (pack -> one grouped ncclSend/ncclRecv per z-neighbour over xGMI -> unpack, all on the engine's
  * stream) and then sph_dispatch.  sph_slab_pack_async / sph_slab_unpack_async are the two halves for hosts that move the
  * buffers themselves (several slab engines in one process, another transport).  Overflows (send buffer, slot capacity)
- * set a device-side flag that sph_slab_status / sph_slab_download report.  A `stream` of NULL at creation means an
- * engine-owned stream: everything above is ordered on THAT stream. */
+ * set a device-side flag that sph_slab_status / sph_slab_download report.  faceCap is also the SIZE OF EVERY MESSAGE and
+ * must be the same on all ranks of a communicator: the first sph_slab_exchange of an engine on a communicator checks
+ * that with one ncclAllReduce (and one stream synchronisation) and fails instead of hanging.  A `stream` of NULL at
+ * creation means an engine-owned stream: everything above is ordered on THAT stream. */
 #define SPH_COMM_ID_BYTES 128
 typedef struct SphComm SphComm;
 int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap);
