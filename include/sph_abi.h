@@ -229,7 +229,11 @@ int sph_upload_particles(SphEngine* e, const SphParticle* host, size_t n);
 /* Read-back of the SSBO (the reference never reads back; needed for parity tests). Synchronises. */
 int sph_download_particles(SphEngine* e, SphParticle* host, size_t n);
 /* Device pointer of the 80-byte AoS in original order: the `ssbo` renderers bind
- * (Scene0p.cpp:1625,2627,3065,3142). Borrowed, read-only, invalidated by reset/destroy. */
+ * (Scene0p.cpp:1625,2627,3065,3142). Borrowed, read-only, invalidated by reset/destroy.
+ * With SPH_OPT_AOS_MODE 1 (default) this call is what brings the records up to date (one
+ * streaming kernel on the engine's stream, no synchronisation): call it once per frame,
+ * before the draw, exactly where Scene0p binds the buffer; the contents then stay valid
+ * until the next dispatch. */
 int sph_device_particles(SphEngine* e, const SphParticle** devPtr);
 /* Render-side export: one float4 (x, y, z, w) per particle in original order into a DEVICE buffer the
  * caller owns (e.g. a GL vertex buffer mapped through HIP-GL interop), replacing the renderers' reads of
