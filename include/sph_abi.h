@@ -239,7 +239,9 @@ int sph_device_particles(SphEngine* e, const SphParticle** devPtr);
  * caller owns (e.g. a GL vertex buffer mapped through HIP-GL interop), replacing the renderers' reads of
  * binding 0 (shaders/fluidDepth.vert:16-24, particleImpostor.vert; Scene0p.cpp:1625,2627,3065).
  * wMode: 0 = 1.0, 1 = density, 2 = foam (padA), 3 = speed |vel|, 4 = dye (padB).  Asynchronous on the
- * engine's stream; n must equal sph_num_particles. */
+ * engine's stream (work the caller has queued on OTHER streams for devOut4, e.g. a fill, is not ordered
+ * against it: finish that first, or hand the engine the caller's stream at creation); n must equal
+ * sph_num_particles. */
 int sph_pack_render_buffer(SphEngine* e, float* devOut4, size_t n, int wMode);
 /* Initial host-side records (SPHFluidGPU::particles: initial state only, never refreshed). */
 int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n);

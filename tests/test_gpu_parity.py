@@ -426,6 +426,7 @@ def test_records_are_materialised_on_demand_by_default(pkg, oracle):
     f.DispatchN(16)                                                  # one frame
     want = oracle.substep(rec, op, steps=16)
     buf = torch.zeros((len(rec), 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                                         # the fill runs on torch's stream, the pack on the engine's own
     f.pack_render_buffer(buf.data_ptr(), 1)                          # first reader: the render pack
     f.sync()
     got = buf.cpu().numpy()
@@ -480,6 +481,7 @@ def test_pack_render_buffer(pkg, oracle, aos):
     f.DispatchN(4)
     want = oracle.substep(rec, to_oracle_params(oracle, sp), steps=4)
     out = torch.zeros((len(rec), 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                      # the fill runs on torch's stream, the pack on the engine's own
     for mode in range(5):
         f.pack_render_buffer(out.data_ptr(), mode)
         f.sync()
@@ -509,6 +511,7 @@ def test_pack_render_buffer_known_answer(pkg):
     rec["density"], rec["pressure"], rec["padA"], rec["padB"] = [10, 20, 30], [7, 7, 7], [0.5, 0.25, 0.125], [0.1, 0.2, 0.3]
     f = make_engine(pkg, rec, sp)
     out = torch.zeros((3, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                      # the fill runs on torch's stream, the pack on the engine's own
     expect = {0: [1, 1, 1], 1: [10, 20, 30], 2: [0.5, 0.25, 0.125], 3: [5, 2, 3], 4: np.float32([0.1, 0.2, 0.3])}
     for mode, w in expect.items():
         f.pack_render_buffer(out.data_ptr(), mode)
