@@ -226,3 +226,29 @@ def test_two_processes_gloo_host_staging(tmp_path):
     out = str(tmp_path / "res.npy")
     mp.spawn(_gloo_worker, args=(2, port, out), nprocs=2, join=True)
     assert np.load(out)[0] == 1
+
+
+def test_bench_two_ranks_rehearsal_over_gloo(tmp_path):
+    """bench.py's N > 1 path end to end (what the driver launches with torch.distributed.run): two ranks on this one
+    GPU, SPH_BENCH_BACKEND=gloo (host-staged halos; RCCL refuses two ranks on one device), BASELINE configs[1] size so
+    that it takes seconds.  Checks the line's contract fields and that no rank dropped halo records."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SPH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config2", "--steps", "6",
+           "--warmup", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["particles"] == 2 * 262144 and "REHEARSAL" in d["config"]["workload"]
+    assert d["slab_status"]["overflow_on_any_rank"] is False
+    lo_hi = d["slab_status"]["records_lo_hi_live_per_rank"]
+    assert lo_hi[0][0] == 0 and lo_hi[0][1] > 0 and lo_hi[1][0] > 0 and lo_hi[1][1] == 0     # each rank has one neighbour
