@@ -113,6 +113,9 @@ __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn
 #ifndef SPH_LIST_LISTU
 #define SPH_LIST_LISTU 4     // list entries fetched together in sweeps 2 / 3
 #endif
+#ifndef SPH_LIST_CHUNKG
+#define SPH_LIST_CHUNKG 4    // candidates filtered per step of the chunked fallback
+#endif
 
 // k_sph_list: one target per lane over the sorted copy.  Sweep 1 walks the 9 contiguous (dy,dz) candidate rows once
 // (density + a list of everything within h of the entry position or within h + eps of the predicted new position);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
                 for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
                 continue;
             }
-            constexpr int G = 4;                               // candidates per step: G loads in flight, one fullness test
+            constexpr int G = SPH_LIST_CHUNKG;                 // candidates per step: G loads in flight, one fullness test
             static_assert(UNROLL + MAXN - G >= 8, "chunk rows");
             for (uint32_t q = a; q < b; q += G) {
                 float4 J[G];
