@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto (config3 at N = 1, weak5 at N > 1) | config2 | config3 | weak5 (BASELINE configs[4] slab)")
     ap.add_argument("--settled-after", type=int, default=300, help="N = 1: after the timed run, continue the SAME run to this substep and record the settled regime (0 = skip)")
-    ap.add_argument("--neighbor", type=int, default=2, help="SPH pass: 2 = k_sph_list (engine default), 1 = k_sph_slow (plain per-target sweeps)")
+    ap.add_argument("--neighbor", type=int, default=3, help="SPH pass: 3 = k_sph_walk (engine default), 2 = k_sph_list (round 2), 1 = k_sph_slow (plain per-target sweeps)")
     ap.add_argument("--aos", default="lazy", choices=["eager", "lazy"], help="lazy (engine default): the 80-byte records are materialised once per frame; eager: by every substep")
     ap.add_argument("--frame-substeps", type=int, default=16, help="lazy, N = 1: materialise the 80-byte record array (sph_device_particles, what a renderer binds) after every this many "
                     "substeps INSIDE the timed region (Scene0p.h:48 maxSubstepsPerFrame = 16) and once more at its end")
@@ -83,8 +83,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` on its own: start the N ranks as a CHILD process (one per GPU, the driver's own
+            # launch line) before anything here has touched the GPU, relay its output and leave with its exit code.
+            # Never an exec: a process that has initialised HIP must not replace itself.
+            import socket
+            import subprocess
+            with socket.socket() as sck:
+                sck.bind(("127.0.0.1", 0))
+                port = sck.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            raise SystemExit(subprocess.run(cmd, env=env).returncode)
         args.gpus = world
 
     import numpy as np
@@ -206,7 +218,7 @@ def main():
         if args.gpus == 1 and args.grid_build == "sort":
             # untimed, for the record: the two other (bit-identical) SPH passes at the state the run has reached
             alt = {}
-            for name, kind in (("k_sph_list", 2), ("k_sph_slow", 1)):
+            for name, kind in (("k_sph_walk", 3), ("k_sph_list", 2), ("k_sph_slow", 1)):
                 sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, kind)
                 sim.set_option(pkg.SPH_OPT_TIMING, 2)
                 sim.kernel_times(reset=True)
@@ -297,7 +309,7 @@ def main():
     traffic = traffic_source = None
     valu = None
     cpath = os.path.join(ROOT, "profiles", "r02_bench_counters.json")
-    kname = "k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list")[args.neighbor]
+    kname = "k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor]
     if os.path.exists(cpath) and args.gpus == 1:
         try:
             cj = json.load(open(cpath))
@@ -320,7 +332,7 @@ def main():
                         + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")"
                         + ("" if backend == "nccl" else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]"),
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
-            "neighbor_kernel": (None, "k_sph_slow", "k_sph_list")[args.neighbor],
+            "neighbor_kernel": (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor],
             "aos": (args.aos if args.gpus > 1 or args.aos == "eager" else
                     f"lazy: 80-byte records materialised (sph_device_particles) every {frame} substeps and at the end, inside the timed region: {records_materialised} times in {args.steps} substeps"),
             "pipeline": (("bin+scan+scatter+rank -> sph(27-cell, OBB fused" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB fused")

@@ -17,6 +17,7 @@
 #include "sph_host.h"
 #include "sph_kernels.h"
 #include "sph_pass.h"
+#include "sph_walk.h"
 
 static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
 
@@ -69,7 +70,7 @@ struct SphEngine {
     uint32_t idBase = 0;
 
     // options
-    int optNeighbor = 2, optGridBuild = 0, optAos = 1, optTiming = 0, optGraph = 0;   // optAos: 1 = records materialised on demand (default)
+    int optNeighbor = 3, optGridBuild = 0, optAos = 1, optTiming = 0, optGraph = 0;   // optAos: 1 = records materialised on demand (default)
     // hipGraph cache of sph_dispatch_n (SPH_OPT_GRAPH): one executable graph per distinct call
     struct GraphEntry {
         uint64_t key = 0;
@@ -113,7 +114,7 @@ struct SphEngine {
     std::vector<float> terrainHeights;      // CPU copy of the heightfield (:175); empty = river step off (:512)
     float* d_terrain = nullptr;             // terrainSSBO (binding 7 of TerrainConstraints.comp)
     size_t terrainCap = 0;
-    float4 *d_sPos = nullptr, *d_sVel = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state (gather2 pass)
+    float4 *d_sPV = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state: 32-byte records (pos, 1/rho | vel, P) + own data
     size_t sortedCap = 0;
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
     float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
@@ -122,7 +123,7 @@ struct SphEngine {
     float lastContainer[15] = {0};          // container / grid members of the last dispatch (a change may move particles by many cells, or the grid under them)
     uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count, [4] flags, [5] / [6] counts of the last async pack
     int debugFlags = 0;
-    unsigned long long* d_stats = nullptr;   // k_sph_list diagnostics (SPH_OPT_DEBUG bit 3), see sph_debug_counters
+    unsigned long long* d_stats = nullptr;   // k_sph_walk / k_sph_list diagnostics (SPH_OPT_DEBUG bit 3), see sph_debug_counters
 
     std::vector<SphParticle> hostInit;   // SPHFluidGPU::particles: initial state only
 
@@ -193,7 +194,7 @@ void free_particle_buffers(SphEngine* e) {
     dev_free(e->d_acc);
     dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
     dev_free(e->d_slabCnt); for (auto& f : e->d_face) dev_free(f);
-    e->faceCap = 0; dev_free(e->d_shapeTab); dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
+    e->faceCap = 0; dev_free(e->d_shapeTab); dev_free(e->d_sPV); dev_free(e->d_sOwn);
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     e->graphs.clear();
     dev_free(e->d_llNext); dev_free(e->d_llCell); dev_free(e->d_llKey);
@@ -293,11 +294,11 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     const int n = (int)(e->slab ? e->nSlots : e->n), C = k.numCells;
     const int nb = blocks_for(n), sb = blocks_for((size_t)C, kScanTile);
     const bool sortedCopy = e->optGridBuild == 0;     // k_rank also writes the sorted copy the SPH pass reads
-    if (sortedCopy && (e->sortedCap < e->cap || !e->d_sPos)) {
+    if (sortedCopy && (e->sortedCap < e->cap || !e->d_sPV)) {
         int rc;
-        dev_free(e->d_sPos); dev_free(e->d_sVel); dev_free(e->d_sOwn);
-        e->d_sPos = e->d_sVel = e->d_sOwn = nullptr; e->sortedCap = 0;
-        if ((rc = dev_alloc(&e->d_sPos, e->cap)) || (rc = dev_alloc(&e->d_sVel, e->cap)) || (rc = dev_alloc(&e->d_sOwn, e->cap))) return rc;
+        dev_free(e->d_sPV); dev_free(e->d_sOwn);
+        e->d_sPV = e->d_sOwn = nullptr; e->sortedCap = 0;
+        if ((rc = dev_alloc(&e->d_sPV, 2 * e->cap)) || (rc = dev_alloc(&e->d_sOwn, e->cap))) return rc;
         e->sortedCap = e->cap;
     }
     if (n) {
@@ -317,11 +318,11 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
                            e->slab ? e->d_slabCnt + 2 : (const uint32_t*)nullptr);
         if (sortedCopy) {
             hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPos, e->d_sVel, e->d_sOwn, k.gx, k.gy,
+                               e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPV, e->d_sOwn, k.gx, k.gy,
                                (commitLive && e->slab) ? e->d_slabCnt + 2 : (uint32_t*)nullptr);
         } else {
             hipLaunchKernelGGL((k_rank<false>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.gx, k.gy,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.gx, k.gy,
                                (commitLive && e->slab) ? e->d_slabCnt + 2 : (uint32_t*)nullptr);
         }
     }
@@ -409,11 +410,19 @@ int dispatch_one(SphEngine* e, float overrideDt) {
     } else {
     if ((rc = build_grid(e, k, true))) return rc;                           // :449-468
     if (n) {                                                                // :470-509 (SPH + OBB fused)
-        if (!e->d_sPos || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
+        if (!e->d_sPV || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
         const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
-        SortedIn S{e->d_sPos, e->d_sVel, e->d_sOwn};
+        SortedIn S{e->d_sPV, e->d_sOwn};
         Timed t(e, SPH_K_SPH);
-        if (e->optNeighbor == 2) {
+        if (e->optNeighbor == 3 && (size_t)n < ((size_t)1 << 27)) {        // (buffer loads address the sorted copy with 32-bit byte offsets)
+            const dim3 grid(8 * ((blocks_for(n, 256) + 7) / 8));
+            if (k.h2 <= 1.0f)
+                hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, e->stream, k, S, in, out,
+                                   e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
+            else
+                hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, e->stream, k, S, in, out,
+                                   e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
+        } else if (e->optNeighbor >= 2) {
             hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n, SPH_LIST_BLOCK) + 7) / 8)), dim3(SPH_LIST_BLOCK), 0, e->stream, k, S, in, out,
                                e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
         } else {
@@ -484,6 +493,16 @@ int dispatch_one(SphEngine* e, float overrideDt) {
 
 namespace {
 using namespace sph;
+
+// Device-side error flags of the exchange (slabCnt[4]) as a status: every entry point that synchronises anyway reports them.
+int slab_flags_error(const SphEngine* e, uint32_t flags, uint32_t nLo, uint32_t nHi) {
+    if (flags & 1u) return fail(SPH_ERR_CAPACITY, "halo send buffer overflowed (%u / %u records for a capacity of %u)", nLo, nHi, e->faceCap);
+    if (flags & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
+    if (flags & 4u) return fail(SPH_ERR_HIP, "a received halo message did not start with a valid header (magic / count): failed or garbled receive");
+    if (flags & 8u) return fail(SPH_ERR_CAPACITY, "a neighbour rank had more halo records than its message could carry (face capacity %u)", e->faceCap);
+    return SPH_OK;
+}
+
 template <class K>
 int launch_impulse(SphEngine* e, const K& kk) {
     int rc;
@@ -632,7 +651,7 @@ int sph_get_params(const SphEngine* e, SphParams* out) {
 int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
-    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 2) return fail(SPH_ERR_ARG, "SPH pass %d: 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 3) return fail(SPH_ERR_ARG, "SPH pass %d: 3 = k_sph_walk, 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;
@@ -681,7 +700,7 @@ static std::vector<unsigned char> graph_material(const SphEngine* e, float dt, i
                          (int)e->idBase, e->allocatedCells, 0};
     add(opts, sizeof(opts));
     const void* ptrs[20] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_vel[0], e->d_vel[1], e->d_rp[0], e->d_rp[1], e->d_foam[0], e->d_foam[1], e->d_acc,
-                            e->d_cellOf, e->d_slotOf, e->d_order, e->d_tmp, e->d_cellCount, e->d_cellStart, e->d_blockSums, e->d_sPos, e->d_sVel, e->d_sOwn};
+                            e->d_cellOf, e->d_slotOf, e->d_order, e->d_tmp, e->d_cellCount, e->d_cellStart, e->d_blockSums, e->d_sPV, e->d_sPV, e->d_sOwn};
     add(ptrs, sizeof(ptrs));
     const void* more[3] = {e->d_llNext, e->d_shapeTab, e->d_stats};
     add(more, sizeof(more));
@@ -1058,6 +1077,11 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
     HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->nSlots = std::min<size_t>(e->nSlots, host[2]);
+    // sph_slab_pack_async / sph_slab_exchange expect zeros in [0..1]; the counts of this pack stay visible to sph_slab_status in [5..6]
+    HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 2 * sizeof(uint32_t), e->stream));
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt + 5, host[0]);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt + 6, host[1]);
+    HIP_TRY(hipGetLastError());
     if (host[0] > capLo || host[1] > capHi) return fail(SPH_ERR_CAPACITY, "halo send buffer too small (%u/%u lo, %u/%u hi)", host[0], capLo, host[1], capHi);
     countsOut[0] = host[0]; countsOut[1] = host[1];
     return SPH_OK;
@@ -1085,10 +1109,13 @@ int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* 
 int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nOut) {
     if (!e || !nOut || (!hostOut && capRecords)) return fail(SPH_ERR_ARG, "null argument");
     if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
-    uint32_t live = 0;
-    HIP_TRY(hipMemcpyAsync(&live, e->d_slabCnt + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    uint32_t cnts[8] = {0};
+    HIP_TRY(hipMemcpyAsync(cnts, e->d_slabCnt, sizeof(cnts), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    const size_t n = live;
+    // a face or slot overflow dropped records: the owned set would come back short without a word
+    int frc = slab_flags_error(e, cnts[4], cnts[0] + cnts[5], cnts[1] + cnts[6]);
+    if (frc) return frc;
+    const size_t n = cnts[2];
     SlabOut* d_out = nullptr;
     int rc;
     if ((rc = dev_alloc(&d_out, n ? n : 1))) return rc;
@@ -1162,7 +1189,7 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_slabCnt, (uint32_t)e->cap);
     if (hi) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, e->stream, hi, lo, recvCap,
                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_slabCnt, (uint32_t)e->cap);
-    hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, lo, hi, (uint32_t)e->cap);
+    hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, lo, hi, (uint32_t)e->cap, recvCap);
     HIP_TRY(hipGetLastError());
     return SPH_OK;
 }
@@ -1174,9 +1201,7 @@ int sph_slab_status(SphEngine* e, uint32_t out[5]) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < 5; ++i) out[i] = host[i];
     out[0] += host[5]; out[1] += host[6];                   // the async pack keeps its counts there (k_slab_headers resets [0], [1])
-    if (host[4] & 1u) return fail(SPH_ERR_CAPACITY, "halo send buffer overflowed (%u / %u records for a capacity of %u)", out[0], out[1], e->faceCap);
-    if (host[4] & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
-    return SPH_OK;
+    return slab_flags_error(e, host[4], out[0], out[1]);
 }
 
 }  // extern "C"
@@ -1272,7 +1297,9 @@ int sph_comm_destroy(SphComm* c) {
 int sph_slab_exchange(SphEngine* e, SphComm* c) {
     if (!e || !c) return fail(SPH_ERR_ARG, "null argument");
     if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
-    if ((e->hasLo && c->rank == 0) || (e->hasHi && c->rank == c->world - 1)) return fail(SPH_ERR_ARG, "slab neighbours do not match rank %d of %d", c->rank, c->world);
+    // both directions: a rank that waits for a neighbour the neighbour does not know about would hang in ncclRecv
+    if ((e->hasLo != 0) != (c->rank > 0) || (e->hasHi != 0) != (c->rank < c->world - 1))
+        return fail(SPH_ERR_ARG, "slab neighbours (lo %d, hi %d) do not match rank %d of %d", e->hasLo, e->hasHi, c->rank, c->world);
     int rc;
     if (e->faceAgreedWith != c) {
         // Once per (engine, communicator): the face capacity is the size of every message, so all ranks must have

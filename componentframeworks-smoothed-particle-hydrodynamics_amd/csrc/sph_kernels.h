@@ -192,14 +192,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
 // (atomic arrival order in k_bin is arbitrary, exactly like BuildGrid.comp's atomicExchange;
 // this pass removes that freedom.)  order[s] = source index of the particle in sorted slot s.
 // With COPY the pass also writes the physically sorted copy of the entry state that the SPH pass
-// reads (sph_pass.h SortedIn: 48 B per particle; 1/rho is the one correctly rounded division per
+// reads (sph_pass.h SortedIn: a 32-byte record + 16 bytes of own data per particle; 1/rho is the one correctly rounded division per
 // neighbour of the numerics contract, item 9).
 template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,
                                                  const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells,
                                                  const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                  const float2* __restrict__ rp, const float* __restrict__ foam,
-                                                 float4* __restrict__ posI, float4* __restrict__ velP, float4* __restrict__ own, int gx, int gy,
+                                                 float4* __restrict__ pv, float4* __restrict__ own, int gx, int gy,
                                                  uint32_t* __restrict__ liveOut) {
     int d = blockIdx.x * kBlock + threadIdx.x;
     // z-slab mode: the sorted output will hold exactly the live particles; their count replaces the slots-in-use count
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, 
     if (COPY) {
         const float4 P = pos[me.y], V = vel[me.y];
         const float2 RP = rp[me.y];
-        posI[s + rank] = make_float4(P.x, P.y, P.z, RP.x > 0.0f ? 1.0f / RP.x : 0.0f);
-        velP[s + rank] = make_float4(V.x, V.y, V.z, RP.y);
+        pv[2u * (s + rank)] = make_float4(P.x, P.y, P.z, RP.x > 0.0f ? 1.0f / RP.x : 0.0f);
+        pv[2u * (s + rank) + 1u] = make_float4(V.x, V.y, V.z, RP.y);
         const uint32_t cxy = c % (uint32_t)(gx * gy);
         const uint32_t cellBits = (cxy % (uint32_t)gx) | ((cxy / (uint32_t)gx) << 10) | ((c / (uint32_t)(gx * gy)) << 20);   // dims <= 1024 (validate_params)
         own[s + rank] = make_float4(bitsf(cellBits), foam[me.y], P.w, V.w);
@@ -813,26 +813,33 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
 }
 
 // ---- exchange without host round trips: the record count travels in a header record in front of the payload ----
+constexpr uint32_t kSlabMagic = 0x48414c4fu;            // "HALO" in the header's flags word
 // counters: [0] records for the lower neighbour, [1] for the upper one, [2] slots in use, [4] error flags
 // (bit 0: a send buffer overflowed, bit 1: the slab's slot capacity overflowed on unpack).
 __global__ void k_slab_headers(uint32_t* __restrict__ counters, SlabRec* __restrict__ sendLo, SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t nl = counters[0], nh = counters[1];
     if (nl > capLo || nh > capHi) atomicOr(&counters[4], 1u);
-    if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nl, capLo); h.flags = 0x48414c4fu; h.pad = nl; sendLo[0] = h; }
-    if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nh, capHi); h.flags = 0x48414c4fu; h.pad = nh; sendHi[0] = h; }
+    if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nl, capLo); h.flags = kSlabMagic; h.pad = nl; sendLo[0] = h; }
+    if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nh, capHi); h.flags = kSlabMagic; h.pad = nh; sendHi[0] = h; }
     counters[5] = nl; counters[6] = nh;                 // what sph_slab_status reports
     counters[0] = 0u; counters[1] = 0u;                 // ready for the next k_slab_pack (no memset between substeps)
+}
+// A received header is trusted only as far as it can be checked: the magic must be there and the count must fit the
+// message; anything else counts as an empty message (k_slab_commit raises the error bit).
+__device__ __forceinline__ uint32_t slab_header_count(const SlabRec* __restrict__ recv, uint32_t recvCap) {
+    const SlabRec h = recv[0];
+    return (h.flags == kSlabMagic && h.id <= recvCap) ? h.id : 0u;
 }
 // recv[0] is the header (id = record count), recv[1..] the payload; appended behind slot counters[2] (+ the other
 // direction's count when `afterOther` points at that header).
 __global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __restrict__ recv, const SlabRec* __restrict__ afterOther, uint32_t recvCap,
                                                             float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
                                                             float* __restrict__ foam, uint32_t* __restrict__ counters, uint32_t slotCap) {
-    const uint32_t cnt = min(recv[0].id, recvCap);
+    const uint32_t cnt = slab_header_count(recv, recvCap);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= cnt) return;
-    const uint32_t base = counters[2] + (afterOther ? afterOther[0].id : 0u);
+    const uint32_t base = counters[2] + (afterOther ? slab_header_count(afterOther, recvCap) : 0u);
     const uint32_t d = base + i;
     if (d >= slotCap) { atomicOr(&counters[4], 2u); return; }
     const SlabRec r = recv[1 + i];
@@ -841,9 +848,19 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __res
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
 }
-__global__ void k_slab_commit(uint32_t* __restrict__ counters, const SlabRec* __restrict__ recvLo, const SlabRec* __restrict__ recvHi, uint32_t slotCap) {
+// counters[4] bit 2: a received header was not a header (magic / count); bit 3: the SENDER had more records than its
+// message could carry (header.pad = its true count), i.e. the neighbour's overflow made visible on this rank too.
+__global__ void k_slab_commit(uint32_t* __restrict__ counters, const SlabRec* __restrict__ recvLo, const SlabRec* __restrict__ recvHi, uint32_t slotCap,
+                              uint32_t recvCap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t add = (recvLo ? recvLo[0].id : 0u) + (recvHi ? recvHi[0].id : 0u);
+    uint32_t add = 0u, err = 0u;
+    for (const SlabRec* r : {recvLo, recvHi}) {
+        if (!r) continue;
+        const SlabRec h = r[0];
+        if (h.flags != kSlabMagic || h.id > recvCap) err |= 4u;
+        else { add += h.id; if (h.pad > h.id) err |= 8u; }
+    }
+    if (err) atomicOr(&counters[4], err);
     counters[2] = min(counters[2] + add, slotCap);
 }
 

@@ -13,9 +13,13 @@
 namespace sph {
 
 struct SortedIn {
-    const float4* __restrict__ posI;   // (x, y, z, 1/rho or 0)  in (cell, id) order of THIS substep
-    const float4* __restrict__ velP;   // (vx, vy, vz, P)
+    // One 32-byte record per particle in (cell, id) order of THIS substep: (x, y, z, 1/rho or 0), (vx, vy, vz, P).
+    // Interleaved since round 3: a neighbour's two halves sit in one cache line, so the walks of sweeps 2 / 3 pull one
+    // line per neighbour instead of two (the walks are bound by the lines their gathers move into L1).
+    const float4* __restrict__ pv;
     const float4* __restrict__ own;    // (bits(cx | cy << 10 | cz << 20), foam, bits(flags), bits(id))
+    __device__ __forceinline__ float4 P(uint32_t q) const { return pv[2u * q]; }          // (x, y, z, 1/rho)
+    __device__ __forceinline__ float4 V(uint32_t q) const { return pv[2u * q + 1u]; }     // (vx, vy, vz, P)
 };   // written by k_rank<true>
 
 __device__ __forceinline__ void store_fields(const SimK& k, const StateOut& out, int s, uint32_t flags, uint32_t id, float px, float py,
@@ -52,7 +56,7 @@ __device__ __forceinline__ bool special_slot(const SimK& k, const SortedIn& S, c
 // One target, everything from global memory, candidates in canonical order.
 __device__ __forceinline__ void sph_slow_one(const SimK& k, const SortedIn& S, const StateIn& in, const StateOut& out,
                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ cellStart, int s) {
-    const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];
+    const float4 P = S.P(s), V = S.V(s), O = S.own[s];
     if (special_slot(k, S, in, out, order, s, P, V, O)) return;
     const uint32_t cb = fbits(O.x);
     const int cx = (int)(cb & 1023u), cy = (int)((cb >> 10) & 1023u), cz = (int)(cb >> 20);
@@ -69,15 +73,15 @@ __device__ __forceinline__ void sph_slow_one(const SimK& k, const SortedIn& S, c
             for (uint32_t q = qs; q < qe; ++q) f(q);
         }
     };
-    rows([&](uint32_t q) { const float4 J = S.posI[q]; pair_density(k, o, J.x, J.y, J.z, (int32_t)-1); });
+    rows([&](uint32_t q) { const float4 J = S.P(q); pair_density(k, o, J.x, J.y, J.z, (int32_t)-1); });
     finish_density(k, o);
     rows([&](uint32_t q) {
-        const float4 J = S.posI[q], JV = S.velP[q];
+        const float4 J = S.P(q), JV = S.V(q);
         pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, (int32_t)((int)q != s ? -1 : 0));
     });
     integrate(k, o);
     rows([&](uint32_t q) {
-        const float4 J = S.posI[q], JV = S.velP[q];
+        const float4 J = S.P(q), JV = S.V(q);
         pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, (int32_t)((int)q != s ? -1 : 0));
     });
     const float foamOut = finish_particle(k, o, O.y);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
     const int sRaw = vb * kB + tid;
     bool live = sRaw < bound;                                // every lane stays to the end (the staging is a wave-wide cooperation)
     const int s = live ? sRaw : max(bound - 1, 0);
-    const float4 P = S.posI[s], V = S.velP[s], O = S.own[s];
+    const float4 P = S.P(s), V = S.V(s), O = S.own[s];
     if (live && special_slot(k, S, in, out, order, s, P, V, O)) live = false;
     Own o;
     own_reset(o);
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
         aN = A; bN = B;
         stagedN = (B - A) <= (uint32_t)CAP && !(dbg & 4);  // wave-uniform
         if (stagedN) {                                     // clamped, unconditional: B - A >= 1 here
-            pre0 = S.posI[A + min((uint32_t)lane, B - A - 1u)];
-            if (CAP > 64) pre1 = S.posI[A + min((uint32_t)lane + 64u, B - A - 1u)];
+            pre0 = S.P(A + min((uint32_t)lane, B - A - 1u));
+            if (CAP > 64) pre1 = S.P(A + min((uint32_t)lane + 64u, B - A - 1u));
         }
     };
     plan(qs[0], qe[0]);
@@ -258,14 +262,13 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
             for (; m < len; ++m) single(wp[m], ebase + m);
             __builtin_amdgcn_wave_barrier();
         } else {
-            const float4* __restrict__ gp = S.posI + q0;
             for (; m + UNROLL <= len; m += UNROLL) {
                 float4 J[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) J[u] = gp[m + (uint32_t)u];
+                for (int u = 0; u < UNROLL; ++u) J[u] = S.P(q0 + m + (uint32_t)u);
                 group(J, ebase + m);
             }
-            for (; m < len; ++m) single(gp[m], ebase + m);
+            for (; m < len; ++m) single(S.P(q0 + m), ebase + m);
         }
     }
     __builtin_amdgcn_wave_barrier();                       // rowA written by lane 0, read by every lane below
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
             for (int u = 0; u < SPH_LIST_LISTU; ++u) {
                 const uint32_t a = nl[min(e + u, count - 1)][tid];
                 const uint32_t q = rowA[wv][a >> 12] + (a & 0xfffu);
-                J[u] = S.posI[q]; JV[u] = S.velP[q];
+                J[u] = S.P(q); JV[u] = S.V(q);
                 ok[u] = (e + u < count && (int)q != s) ? -1 : 0;
             }
 #pragma unroll
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
             const uint32_t base = rowA[wv][r];                 // <= a: the wave's union of this row starts at or before this lane's run
             if (b - base > 4095u || base > a) {                // offsets beyond the entry format: plain sweep of this run
                 listed(c, f); c = 0;
-                for (uint32_t q = a; q < b; ++q) f(S.posI[q], S.velP[q], (int32_t)((int)q != s ? -1 : 0));
+                for (uint32_t q = a; q < b; ++q) f(S.P(q), S.V(q), (int32_t)((int)q != s ? -1 : 0));
                 continue;
             }
             constexpr int G = SPH_LIST_CHUNKG;                 // candidates per step: G loads in flight, one fullness test
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
             for (uint32_t q = a; q < b; q += G) {
                 float4 J[G];
 #pragma unroll
-                for (int u = 0; u < G; ++u) J[u] = S.posI[min(q + (uint32_t)u, b - 1u)];
+                for (int u = 0; u < G; ++u) J[u] = S.P(min(q + (uint32_t)u, b - 1u));
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const float dx = cpx - J[u].x, dy = cpy - J[u].y, dz = cpz - J[u].z;

@@ -1,9 +1,12 @@
 """Parity of the HIP path (through the C-ABI) with the CPU oracle, on the MI355X.
 
-Bar: BIT-EXACT on every field of the 80-byte record.  The engine's arithmetic contract
-(DESIGN.md "Numerics") fixes operation order, fma placement and reciprocal forms, and the
-oracle restates the same contract, so the fp32 tolerance BASELINE.json allows (1e-4 relative
-on density/pressure after 100 substeps) is met with zero error; tests that pass through
+Bar: BIT-EXACT on every field of the 80-byte record AGAINST THE ENGINE'S OWN ARITHMETIC CONTRACT (oracle contract 1,
+DESIGN.md section 3: operation order, fma placement, the specified rsqrt and reciprocal forms, restated identically
+by the oracle).  That is a statement about the kernels (every variant, every fallback, any decomposition gives the same
+bits), not about the distance to the literal shader arithmetic: the literal restatement of SPHFluid.comp (contract 0)
+differs from the contract by fp32 rounding, and tests/test_gpu_parity_full.py bounds that difference on the device path
+(1e-6 .. 1e-3 relative density over 1 .. 50 substeps of the collapsing config 1; 1e-4 over 100 substeps of a settled
+pool, which is BASELINE.json's tolerance in the form the reference can meet against itself).  Tests that pass through
 libm-dependent code say so explicitly.
 """
 import numpy as np
@@ -13,10 +16,10 @@ from conftest import assert_records_equal, small_scene, to_oracle_params
 
 pytestmark = pytest.mark.gpu
 
-NEIGHBOR_VARIANTS = [("slow", 1), ("list", 2)]      # k_sph_slow (plain statement) and k_sph_list (default)
+NEIGHBOR_VARIANTS = [("slow", 1), ("list", 2), ("walk", 3)]      # k_sph_slow (plain statement), k_sph_list (round 2) and k_sph_walk (round 3)
 
 
-def make_engine(pkg, rec, sp, neighbor=2, debug=0, aos_lazy=False):
+def make_engine(pkg, rec, sp, neighbor=3, debug=0, aos_lazy=False):
     f = pkg.SPHFluidGPU.from_particles(rec, sp)
     f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, neighbor)
     if debug:
@@ -62,8 +65,9 @@ def test_substeps_bit_exact(pkg, oracle, name, neighbor, steps):
 
 @pytest.mark.parametrize("name,neighbor", NEIGHBOR_VARIANTS)
 def test_config1_100_substeps(pkg, oracle, name, neighbor):
-    """BASELINE.json parity run: config-1 inputs (32768 particles, 32^3 grid), 100 substeps,
-    per-particle density and pressure within 1e-4 relative of the CPU reference (here: equal)."""
+    """BASELINE.json parity run: config-1 inputs (32768 particles, 32^3 grid), 100 substeps, against the oracle under the
+    engine's contract: equal bits (which trivially meets 1e-4).  Against the literal shader arithmetic this collapsing scene
+    diverges chaotically by 100 substeps; see test_gpu_parity_full.py for what holds there."""
     syn = pkg.synthetic
     cfg = syn.CONFIGS[1]
     rec, _ = syn.make_particles(cfg)
@@ -81,13 +85,14 @@ def test_config1_100_substeps(pkg, oracle, name, neighbor):
     f.close()
 
 
+@pytest.mark.parametrize("kernel", [2, 3])
 @pytest.mark.parametrize("debug", [1, 2, 3, 4, 7])
-def test_list_fallback_paths_bit_exact(pkg, oracle, debug):
+def test_list_fallback_paths_bit_exact(pkg, oracle, debug, kernel):
     """k_sph_list's exact fallbacks forced for every target -- bit 0: neighbour-list overflow (full candidate sweeps
     2 and 3), bit 1: a target outside the list's slack after integrate (full sweep 3), bit 2: no LDS windows
     (per-lane global loads in sweep 1).  Identical bits."""
     rec, sp = small_scene(pkg, n=4096, grid=16, seed=33)
-    f = make_engine(pkg, rec, sp, 2, debug=debug | 8)
+    f = make_engine(pkg, rec, sp, kernel, debug=debug | 8)
     f.DispatchN(5)
     assert_records_equal(f.download(), oracle.substep(rec, to_oracle_params(oracle, sp), steps=5), f"debug={debug}")
     c = f.debug_counters()
@@ -96,10 +101,11 @@ def test_list_fallback_paths_bit_exact(pkg, oracle, debug):
     f.close()
 
 
-def test_list_fast_path_is_the_one_running(pkg, oracle):
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_list_fast_path_is_the_one_running(pkg, oracle, kernel):
     """On the lattice scene nothing may fall back: the lists hold every target's neighbours."""
     rec, sp = small_scene(pkg, n=4096, grid=16, seed=33)
-    f = make_engine(pkg, rec, sp, 2, debug=8)
+    f = make_engine(pkg, rec, sp, kernel, debug=8)
     f.DispatchN(5)
     c = f.debug_counters()
     assert_records_equal(f.download(), oracle.substep(rec, to_oracle_params(oracle, sp), steps=5), "fast path")
@@ -147,7 +153,7 @@ def test_container_shapes(pkg, oracle, shape):
     f.close()
 
 
-@pytest.mark.parametrize("neighbor,aos", [(1, 0), (2, 1), (2, 0)])
+@pytest.mark.parametrize("neighbor,aos", [(1, 0), (2, 1), (3, 1), (3, 0)])
 def test_ext_shape_other_paths(pkg, oracle, neighbor, aos):
     """A deferred-OBB shape through the gather kernel and with the lazy 80-byte array; the shape
     changes between dispatches (table re-upload), as the ImGui shape picker does (Scene0p.cpp:2380-2470)."""
@@ -284,7 +290,7 @@ def test_all_particles_in_one_cell(pkg, oracle):
         f.close()
 
 
-@pytest.mark.parametrize("neighbor", [2, 1])
+@pytest.mark.parametrize("neighbor", [3, 2, 1])
 def test_download_grid_before_first_dispatch(pkg, oracle, neighbor):
     """sph_download_grid enters the grid build (k_rank writes the sorted copy) BEFORE any dispatch, again after an upload
     and after ResetSimulation re-allocated every buffer: the sorted copy must exist on each of these entries (the round-1
@@ -315,18 +321,20 @@ def test_download_grid_before_first_dispatch(pkg, oracle, neighbor):
 
 def test_full_size_properties_config3(pkg):
     """4M particles / 128^3 (BASELINE.json configs[2]) is too big for the oracle in a test, so
-    check size-independent properties: k_sph_list == k_sph_slow bit for bit, velocity cap, containment."""
+    check size-independent properties: k_sph_slow == k_sph_list == k_sph_walk bit for bit, velocity cap, containment.
+    (The same size against the ORACLE: tests/test_gpu_parity_full.py.)"""
     syn = pkg.synthetic
     cfg = syn.CONFIGS[3]
     rec, _ = syn.make_particles(cfg)
     sp = pkg.default_params(**syn.params_fields(cfg))
     outs = []
-    for neighbor in (1, 2):
+    for neighbor in (1, 2, 3):
         f = make_engine(pkg, rec, sp, neighbor)
         f.DispatchN(3)
         outs.append(f.download())
         f.close()
     assert_records_equal(outs[0], outs[1], "k_sph_slow vs k_sph_list at 4M")
+    assert_records_equal(outs[0], outs[2], "k_sph_slow vs k_sph_walk at 4M")
     out = outs[0]
     half = syn.box_half_for_grid(cfg.grid)
     assert np.all(np.abs(out["pos"][:, :3]) <= half[None, :] + 1e-4)

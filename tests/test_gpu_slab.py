@@ -29,7 +29,7 @@ def _cell_z(pkg, sp, P):
     return np.clip(np.floor(q), 0, g.dims[2] - 1).astype(np.int64), tuple(g.dims)
 
 
-def _group(pkg, halo, P, sp, world, neighbor=2):
+def _group(pkg, halo, P, sp, world, neighbor=3):
     import torch
     cz, dims = _cell_z(pkg, sp, P)
     ids = np.arange(len(P), dtype=np.uint32)
@@ -43,7 +43,7 @@ def _group(pkg, halo, P, sp, world, neighbor=2):
                                          lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), 8192, cz)
 
 
-@pytest.mark.parametrize("neighbor", [1, 2])
+@pytest.mark.parametrize("neighbor", [1, 2, 3])
 @pytest.mark.parametrize("world", [1, 2, 3, 5])
 def test_slabs_match_single_engine_and_oracle(pkg, oracle, world, neighbor):
     halo = importlib.import_module(PKG_NAME + ".halo")
@@ -252,3 +252,19 @@ def test_bench_two_ranks_rehearsal_over_gloo(tmp_path):
     assert d["slab_status"]["overflow_on_any_rank"] is False
     lo_hi = d["slab_status"]["records_lo_hi_live_per_rank"]
     assert lo_hi[0][0] == 0 and lo_hi[0][1] > 0 and lo_hi[1][0] > 0 and lo_hi[1][1] == 0     # each rank has one neighbour
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the form the driver uses at N = 1, extended to N > 1): bench.py
+    starts torch.distributed.run itself as a child process before touching the GPU and relays the one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SPH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["slab_status"]["overflow_on_any_rank"] is False

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_sph_list diagnostics (SPH_OPT_DEBUG bit 3): fallbacks, list entries and staged candidates per substep.
-usage: pair_stats.py [config index=3] [substeps=5] [compare-with-slow 0|1]"""
+usage: list_stats.py [config index=3] [substeps=5] [compare-with-slow 0|1] [kernel 2|3]"""
 import importlib, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,10 +10,12 @@ syn = pkg.synthetic
 ci = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cmp_slow = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+kernel = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 cfg = syn.CONFIGS[ci]
 rec, _ = syn.make_particles(cfg)
 sp = pkg.default_params(**syn.params_fields(cfg))
 f = pkg.SPHFluidGPU.from_particles(rec, sp)
+f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, kernel)
 f.set_option(pkg.SPH_OPT_DEBUG, 8)
 g = None
 if cmp_slow:
@@ -24,7 +26,7 @@ for s in range(steps):
     c = f.debug_counters(reset=True)
     lanes = max(c["lanes"], 1)
     row = {"substep": s, "fallback_targets": c["slow_targets"], "overflow": c["overflow_targets"], "far": c["far_targets"],
-           "waves_with_fallback": c["waves_with_fallback"], "waves": lanes // 64, "entries_per_lane": round(c["list_entries"] / lanes, 2)}
+           "waves_with_fallback": c["waves_with_fallback"], "waves": lanes // 64, "rows_unstaged": c["slow_waves"], "rows": c["window_candidates"], "entries_per_lane": round(c["list_entries"] / lanes, 2)}
     if g is not None:
         g.DispatchCompute()
         a, b = f.download(), g.download()

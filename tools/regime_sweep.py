@@ -2,7 +2,7 @@
 """SPH-pass time along the trajectory of a bench workload (the fluid column of configs[2] collapses,
 DESIGN.md section 6).  The passes are bit-identical, so switching between them does not perturb the run.
 usage: regime_sweep.py [config index=3] [last step=300] [stride=25] [passes, e.g. 2,0,1]
-pass ids: 2 k_sph_list, 1 k_sph_slow"""
+pass ids: 3 k_sph_walk, 2 k_sph_list, 1 k_sph_slow"""
 import importlib
 import json
 import os
@@ -42,7 +42,7 @@ step = 0
 while step <= last:
     row = {"step": step}
     for kind in kinds:
-        row[{2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
+        row[{3: "walk", 2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
         step += REPS
     print(json.dumps(row), flush=True)
     select(2)

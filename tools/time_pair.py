@@ -14,7 +14,7 @@ cfg = syn.CONFIGS[ci]
 rec, _ = syn.make_particles(cfg)
 sp = pkg.default_params(**syn.params_fields(cfg))
 outs = {}
-for nb in ((2, 1) if check else (2,)):
+for nb in ((3, 1) if check else (3,)):
     f = pkg.SPHFluidGPU.from_particles(rec, sp)
     f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, nb)
     f.DispatchN(warm)
@@ -27,5 +27,5 @@ for nb in ((2, 1) if check else (2,)):
         outs[nb] = f.download()
     f.close()
 if check:
-    a, b = outs[2], outs[1]
+    a, b = outs[3], outs[1]
     print("identical" if a.tobytes() == b.tobytes() else f"DIFFER in {int((a.view(np.uint8).reshape(len(a), -1) != b.view(np.uint8).reshape(len(b), -1)).any(axis=1).sum())} records")
