@@ -51,6 +51,16 @@ def parse():
 def cpu_baseline(pkg, rec, sp, cpu_steps):
     """The oracle (OpenMP port of the same shader math) timed on this host's cores, on the
     same particle set; the sample is a reduced number of substeps of the same workload."""
+    # SURVEY.md 8(d): the CPU baseline is the oracle built -O3 -march=native ON THE HOST THAT RUNS IT (the in-tree
+    # liboracle.so is built in the build container for a generic AVX2 host, so that it runs anywhere).  Same source, same
+    # -ffp-contract=off: same bits, only the instruction selection differs.
+    import subprocess
+    import tempfile
+    native = os.path.join(tempfile.gettempdir(), f"liboracle_native_{os.getuid()}.so")
+    flags = "-O3 -march=native -std=c11 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -shared"
+    built = subprocess.run(["gcc", *flags.split(), "-o", native, os.path.join(ROOT, "oracle", "sph_oracle.c"), "-lm"], capture_output=True, text=True)
+    if built.returncode == 0:
+        os.environ["SPH_ORACLE_LIB"] = native
     from oracle import oracle as o
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import to_oracle_params
@@ -73,7 +83,8 @@ def cpu_baseline(pkg, rec, sp, cpu_steps):
     t = run(k)
     return {
         "value": len(rec) * k / t, "unit": "particle-substeps/s", "cores": threads, "kind": "port",
-        "sample": f"{k} substeps of the same {len(rec)}-particle workload (after 1 warm-up substep), oracle/sph_oracle.c with OpenMP, {t:.2f} s",
+        "sample": f"{k} substeps of the same {len(rec)}-particle workload (after 1 warm-up substep), oracle/sph_oracle.c with OpenMP, "
+                  + ("gcc -O3 -march=native on this host" if built.returncode == 0 else "in-tree -O3 -mavx2 build (native build failed)") + f", {t:.2f} s",
     }
 
 
@@ -303,25 +314,33 @@ def main():
     sph_avg_s = (sph_ms / max(sph_launches, 1)) * 1e-3
     alg_bytes = 164 * n_local + 4 * C_local          # SPHFluid pass, per launch
     achieved = alg_bytes / sph_avg_s / 1e9 if sph_avg_s > 0 else 0.0
-    # HBM traffic and VALU instruction counts are NOT measured in this run: they come from separate rocprofv3 --pmc
-    # passes over this same command (tools/profile_bench.sh), summarised for exactly the timed launches in
-    # profiles/r02_bench_counters.json; the line says so in traffic_source / valu.source.
+    # HBM traffic, VALU instruction counts and L1 cache-line accesses are NOT measured in this run: they come from separate
+    # rocprofv3 --pmc passes over this same command (tools/profile_bench.sh), summarised for exactly the timed launches in
+    # profiles/r03_bench_counters.json.  That file carries the hash of the engine sources it was measured on; a file from
+    # other sources is refused (traffic stays null and traffic_source says why).
     traffic = traffic_source = None
     valu = None
-    cpath = os.path.join(ROOT, "profiles", "r02_bench_counters.json")
+    cpath = os.path.join(ROOT, "profiles", "r03_bench_counters.json")
     kname = "k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor]
     if os.path.exists(cpath) and args.gpus == 1:
         try:
             cj = json.load(open(cpath))
-            if cj.get("workload") == wl and cj.get("kernel") == kname:
+            here = pkg.build.csrc_hash()
+            if cj.get("csrc_hash") != here:
+                traffic_source = f"profiles/r03_bench_counters.json was measured on other engine sources ({cj.get('csrc_hash')} != {here}): not used"
+            elif cj.get("workload") == wl and cj.get("kernel") == kname:
                 traffic = cj.get("hbm_bytes_per_launch")
                 traffic_source = cj.get("source")
                 if cj.get("valu_wave_insts_per_launch") and sph_avg_s > 0:
-                    peak = 256 * 4 * 2.4e9 / 4.0          # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
-                    valu = {"wave_insts_per_launch": cj["valu_wave_insts_per_launch"], "issue_peak_per_s": peak,
-                            "frac_of_issue_peak": cj["valu_wave_insts_per_launch"] / sph_avg_s / peak, "source": cj.get("source")}
-        except Exception:
-            traffic = None
+                    # issue cost measured on gfx950 (profiles/r03_valu_rate2.txt): about 1.05 ns per wave-instruction and SIMD for the
+                    # add / mul / fma / integer add-and-or class, 1.75 ns for v_pk_*, v_cmp, v_cndmask, v_max/min and the VOP3-only forms
+                    valu = {"wave_insts_per_launch": cj["valu_wave_insts_per_launch"],
+                            "wave_insts_per_s_per_simd": cj["valu_wave_insts_per_launch"] / sph_avg_s / 1024.0,
+                            "tcp_line_accesses_per_launch": cj.get("tcp_line_accesses_per_launch"),
+                            "tcp_line_accesses_per_cycle_per_cu_at_2GHz": (cj["tcp_line_accesses_per_launch"] / 256.0 / (sph_avg_s * 2.0e9)) if cj.get("tcp_line_accesses_per_launch") else None,
+                            "source": cj.get("source")}
+        except Exception as ex:                              # noqa: BLE001
+            traffic, traffic_source = None, f"profiles/r03_bench_counters.json unreadable: {ex}"
 
     out = {
         "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-substeps/s",
@@ -343,8 +362,10 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
             "window": {"kernel": kname, "first_launch": args.warmup, "launches": int(sph_launches),
-                       "note": "0-based index among this kernel's launches of the run; profiles/r02_bench_kernel_window.json holds the rocprofv3 --kernel-trace average of exactly these launches"},
+                       "note": "0-based index among this kernel's launches of the run; profiles/r03_bench_kernel_window.json holds the rocprofv3 --kernel-trace average of exactly these launches"},
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
+            # the same window with the 80-byte records updated by EVERY substep (what the 164 N figure prices; aos_eager below)
+            "frac_records_updated_every_substep": (alg_bytes / (aos_eager["sph_pass_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if aos_eager and aos_eager.get("sph_pass_us") else None,
             "whole_substep_algorithmic_GBs": (260 * n_local + 8 * C_local) / (elapsed / args.steps) / 1e9,
         },
         "kernels_us_per_substep": breakdown,

@@ -29,6 +29,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP engine cannot be built")
 
 
+def csrc_hash() -> str:
+    """sha256 over the engine's sources (and the flags they are built with): ties a profile under profiles/ to the code it measured."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

@@ -5,7 +5,7 @@
     rocpd_summary.py pmc    <results.db> <out.json> [substr]  # --pmc run -> mean counter values per kernel
     rocpd_summary.py traffic <fetch.db> <write.db> <kernel substr> <workload> <neighbor> <out.json>
     rocpd_summary.py window <stats.db> <kernel substr> <first launch> <count> <out.json>     # exactly bench.py's timed launches
-    rocpd_summary.py bench-counters <fetch.db> <write.db> <valu.db> <kernel> <first> <count> <workload> <source> <out.json>
+    rocpd_summary.py bench-counters <fetch.db> <write.db> <valu.db> <kernel> <first> <count> <workload> <source> <out.json> [<tcp.db> <csrc hash>]
 
 traffic: HBM bytes per launch of the dominant kernel as /opt/skills/guides/MI355X_MICROARCH.md prescribes
 (FETCH_SIZE / WRITE_SIZE from separate passes, KiB units; on gfx950 FETCH_SIZE tallies 128-byte requests at
@@ -68,6 +68,8 @@ def main():
         return
     if mode == "bench-counters":  # bench-counters <fetch.db> <write.db> <valu.db> <kernel> <first> <count> <workload> <source text> <out.json>
         fdb, wdb, vdb, kernel, first, count, workload, source, out = sys.argv[2:11]
+        tdb = sys.argv[11] if len(sys.argv) > 11 else None          # optional: TCP_TOTAL_CACHE_ACCESSES_sum pass
+        csrc = sys.argv[12] if len(sys.argv) > 12 else None         # optional: hash of the engine sources the passes ran on
         first, count = int(first), int(count)
         f = window_counter(fdb, kernel, "FETCH_SIZE", first, count)
         w = window_counter(wdb, kernel, "WRITE_SIZE", first, count)
@@ -76,6 +78,10 @@ def main():
                "fetch_size_kib_raw": f["mean"], "write_size_kib_raw": w["mean"],
                "correction": "read side doubled (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); write side as reported",
                "hbm_bytes_per_launch": (2.0 * f["mean"] + w["mean"]) * 1024.0, "valu_wave_insts_per_launch": v["mean"], "source": source}
+        if tdb:
+            res["tcp_line_accesses_per_launch"] = window_counter(tdb, kernel, "TCP_TOTAL_CACHE_ACCESSES_sum", first, count)["mean"]
+        if csrc:
+            res["csrc_hash"] = csrc
         json.dump(res, open(out, "w"), indent=1)
         print(json.dumps(res))
         return
