@@ -119,6 +119,11 @@ struct SphEngine {
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
     float shapeKey[8] = {-1.0f};            // parameters the uploaded table was built from
     sph::ShapeTab shapeTab{};
+    // boundary-first substep (sph_slab_step_*): the halo exchange of the NEXT substep runs on xstream beside the interior of the SPH pass
+    hipStream_t xstream = nullptr;
+    hipEvent_t evBoundary = nullptr, evPacked = nullptr, evDone = nullptr;
+    hipEvent_t peerDone[2] = {nullptr, nullptr};   // evDone of the lower / upper neighbour ENGINE of the last local transfer: it has read this engine's send face
+    bool stepPending = false;               // sph_slab_step_begin ran, its finish has not yet
     bool slabOrderValid = false;            // slots are in the order of the last counting sort and no particle can have moved by more than a layer since
     float lastContainer[15] = {0};          // container / grid members of the last dispatch (a change may move particles by many cells, or the grid under them)
     uint32_t* d_slabCnt = nullptr;          // [0] lo records, [1] hi records, [2] live count, [3] download count, [4] flags, [5] / [6] counts of the last async pack
@@ -156,6 +161,7 @@ bool slab_ranges_usable(const SphEngine* e) {
 int flush_events(SphEngine* e) {
     if (e->evLive.empty()) return SPH_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->xstream) HIP_TRY(hipStreamSynchronize(e->xstream));
     for (auto& ev : e->evLive) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
@@ -171,18 +177,19 @@ struct Timed {   // RAII-ish bracket around one kernel launch when SPH_OPT_TIMIN
     SphEngine* e;
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(SphEngine* e_, int cls_) : e(e_), cls(cls_) {
+    hipStream_t st;
+    Timed(SphEngine* e_, int cls_, hipStream_t st_ = nullptr) : e(e_), cls(cls_), st(st_ ? st_ : e_->stream) {
         if (!e->optTiming || (e->optTiming == 2 && cls != SPH_K_SPH)) return;
         if (e->evPool.empty()) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         } else {
             a = e->evPool.back().first; b = e->evPool.back().second; e->evPool.pop_back();
         }
-        (void)hipEventRecord(a, e->stream);
+        (void)hipEventRecord(a, st);
     }
     ~Timed() {
         if (!a) return;
-        (void)hipEventRecord(b, e->stream);
+        (void)hipEventRecord(b, st);
         e->evLive.push_back({cls, a, b});
         if (e->evLive.size() >= 8192) (void)flush_events(e);
     }
@@ -367,8 +374,10 @@ int ensure_shape_table(SphEngine* e) {
     return SPH_OK;
 }
 
-int dispatch_one(SphEngine* e, float overrideDt) {
-    if (e->params.param_pause) return SPH_OK;                               // SPHFluid3D.cpp:432
+// boundaryFirst (z-slab engines, sph_slab_step_begin): the SPH pass runs the slot ranges next to the slab's faces first and
+// records e->evBoundary behind them, so that the pack of the next exchange can start while the interior is computed.
+int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
+    if (e->params.param_pause) { if (boundaryFirst) HIP_TRY(hipEventRecord(e->evBoundary, e->stream)); return SPH_OK; }                               // SPHFluid3D.cpp:432
     int rc;
     if ((rc = validate_params(e->params))) return rc;
     const float dt = overrideDt > 0.0f ? overrideDt : e->params.param_timeStep;   // :434
@@ -416,12 +425,30 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         Timed t(e, SPH_K_SPH);
         if (e->optNeighbor == 3 && (size_t)n < ((size_t)1 << 27)) {        // (buffer loads address the sorted copy with 32-bit byte offsets)
             const dim3 grid(8 * ((blocks_for(n, 256) + 7) / 8));
-            if (k.h2 <= 1.0f)
-                hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, e->stream, k, S, in, out,
-                                   e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
-            else
-                hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, e->stream, k, S, in, out,
-                                   e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
+            auto walk = [&](const uint32_t* lo, const uint32_t* hi) {
+                if (k.h2 <= 1.0f)
+                    hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, e->stream, k, S, in, out,
+                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi);
+                else
+                    hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, e->stream, k, S, in, out,
+                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi);
+            };
+            // The pack of the next exchange only reads the slots of the three lowest / three highest local cell layers (k_slab_pack,
+            // under the same conditions): those two slot ranges first, the event, then everything in between.
+            float contNow[15];
+            container_key(e->params, contNow);
+            const bool split = boundaryFirst && e->slab && k.gz > 6 && !k.obbDeferred && std::memcmp(contNow, e->lastContainer, sizeof(contNow)) == 0;
+            if (split) {
+                const uint32_t* endLo = e->d_cellStart + 3 * (size_t)(k.gx * k.gy);
+                const uint32_t* startHi = e->d_cellStart + (size_t)(k.gz - 3) * (size_t)(k.gx * k.gy);
+                walk(nullptr, endLo);
+                walk(startHi, nullptr);
+                HIP_TRY(hipEventRecord(e->evBoundary, e->stream));
+                boundaryFirst = false;                                     // recorded
+                walk(endLo, startHi);
+            } else {
+                walk(nullptr, nullptr);
+            }
         } else if (e->optNeighbor >= 2) {
             hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n, SPH_LIST_BLOCK) + 7) / 8)), dim3(SPH_LIST_BLOCK), 0, e->stream, k, S, in, out,
                                e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
@@ -470,6 +497,7 @@ int dispatch_one(SphEngine* e, float overrideDt) {
         e->fountain.fountainSeed++;
     }
     HIP_TRY(hipGetLastError());
+    if (boundaryFirst) HIP_TRY(hipEventRecord(e->evBoundary, e->stream));   // no split launch: the pack waits for the whole pass
     e->cur = nx;
     e->accValid = !fuseAos;
     e->aosValid = fuseAos;
@@ -605,6 +633,7 @@ int sph_create_from_particles(SphEngine** out, const SphParticle* particles, siz
 int sph_destroy(SphEngine* e) {
     if (!e) return SPH_OK;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->xstream) (void)hipStreamSynchronize(e->xstream);
     free_particle_buffers(e);
     free_grid_buffers(e);
     dev_free(e->d_dbg);
@@ -613,6 +642,8 @@ int sph_destroy(SphEngine* e) {
     dev_free(e->d_stats);
     for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (e->xstream) { (void)hipStreamSynchronize(e->xstream); (void)hipStreamDestroy(e->xstream); }
+    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone}) if (ev) (void)hipEventDestroy(ev);
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return SPH_OK;
@@ -1069,7 +1100,7 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
     if (e->nSlots) {
         Timed t(e, SPH_K_OTHER);
         hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->nSlots)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
-                           e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], (int)e->nSlots,
+                           e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->accValid ? e->d_acc : (const float4*)nullptr, (int)e->nSlots,
                            (SlabRec*)sendLo, (SlabRec*)sendHi, capLo, capHi, e->d_slabCnt,
                            slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
     }
@@ -1094,10 +1125,10 @@ int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* 
     if (e->nSlots + nLo + nHi > e->cap) return fail(SPH_ERR_CAPACITY, "slab capacity %zu < %zu slots", e->cap, e->nSlots + nLo + nHi);
     const int c = e->cur;
     if (nLo) hipLaunchKernelGGL(k_slab_unpack, dim3(blocks_for(nLo)), dim3(kBlock), 0, e->stream, (const SlabRec*)recvLo, (int)nLo,
-                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], (int)e->nSlots);
+                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, (int)e->nSlots);
     e->nSlots += nLo;
     if (nHi) hipLaunchKernelGGL(k_slab_unpack, dim3(blocks_for(nHi)), dim3(kBlock), 0, e->stream, (const SlabRec*)recvHi, (int)nHi,
-                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], (int)e->nSlots);
+                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, (int)e->nSlots);
     e->nSlots += nHi;
     HIP_TRY(hipGetLastError());
     // until the next dispatch sorts again, every slot may hold data
@@ -1157,7 +1188,7 @@ int sph_slab_face_buffer(SphEngine* e, int which, void** devPtr) {
     *devPtr = e->d_face[which];
     return SPH_OK;
 }
-int sph_slab_pack_async(SphEngine* e) {
+static int slab_pack_on(SphEngine* e, hipStream_t st) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
     sph::compute_grid_extents(e->params, e->grid);
@@ -1165,18 +1196,18 @@ int sph_slab_pack_async(SphEngine* e) {
     make_simk(e->params, e->grid, e->params.param_timeStep, k);
     e->nSlots = e->cap;                                     // from now on only a launch bound: slabCnt[2] counts the slots in use
     {                                                       // (slabCnt[0..1] are zero: set at creation, reset by k_slab_headers)
-        Timed t(e, SPH_K_OTHER);
-        hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->cap)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
-                           e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], (int)e->cap,
+        Timed t(e, SPH_K_OTHER, st);
+        hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->cap)), dim3(kBlock), 0, st, k, e->z0, e->z1, e->hasLo, e->hasHi,
+                           e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->accValid ? e->d_acc : (const float4*)nullptr, (int)e->cap,
                            e->d_face[0] + 1, e->d_face[1] + 1, e->faceCap, e->faceCap, e->d_slabCnt,
                            slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
-        hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, e->hasLo ? e->d_face[0] : (SlabRec*)nullptr,
+        hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, st, e->d_slabCnt, e->hasLo ? e->d_face[0] : (SlabRec*)nullptr,
                            e->hasHi ? e->d_face[1] : (SlabRec*)nullptr, e->faceCap, e->faceCap);
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
 }
-int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap) {
+static int slab_unpack_on(SphEngine* e, hipStream_t st, const void* recvLo, const void* recvHi, uint32_t recvCap) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
     const SlabRec* lo = e->hasLo ? (const SlabRec*)recvLo : nullptr;
@@ -1184,13 +1215,72 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
     if ((e->hasLo && !lo) || (e->hasHi && !hi)) return fail(SPH_ERR_ARG, "missing receive buffer");
     const int c = e->cur;
     e->nSlots = e->cap;
-    Timed t(e, SPH_K_OTHER);
-    if (lo) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, e->stream, lo, (const SlabRec*)nullptr, recvCap,
-                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_slabCnt, (uint32_t)e->cap);
-    if (hi) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, e->stream, hi, lo, recvCap,
-                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_slabCnt, (uint32_t)e->cap);
-    hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, e->stream, e->d_slabCnt, lo, hi, (uint32_t)e->cap, recvCap);
+    Timed t(e, SPH_K_OTHER, st);
+    if (lo) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, st, lo, (const SlabRec*)nullptr, recvCap,
+                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap);
+    if (hi) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, st, hi, lo, recvCap,
+                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap);
+    hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, st, e->d_slabCnt, lo, hi, (uint32_t)e->cap, recvCap);
     HIP_TRY(hipGetLastError());
+    return SPH_OK;
+}
+int sph_slab_pack_async(SphEngine* e) { return e ? slab_pack_on(e, e->stream) : fail(SPH_ERR_ARG, "null engine"); }
+int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap) {
+    return e ? slab_unpack_on(e, e->stream, recvLo, recvHi, recvCap) : fail(SPH_ERR_ARG, "null engine");
+}
+
+// ---- boundary-first substep: the exchange of the next substep beside the interior of this one -------------------------
+static int ensure_xstream(SphEngine* e) {
+    if (e->xstream) return SPH_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->evBoundary, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->evPacked, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->evDone, hipEventDisableTiming));
+    return SPH_OK;
+}
+int sph_slab_step_begin(SphEngine* e, float overrideDt) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
+    if (e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_begin twice without sph_slab_step_finish / sph_slab_step_finish_local");
+    int rc;
+    if ((rc = ensure_xstream(e))) return rc;
+    if ((rc = dispatch_one(e, overrideDt, true))) return rc;               // ... -> SPH (faces first, e->evBoundary, interior) on the engine's stream
+    HIP_TRY(hipStreamWaitEvent(e->xstream, e->evBoundary, 0));
+    for (hipEvent_t ev : e->peerDone)                                        // a neighbour engine of this process may still be copying the last send face
+        if (ev) HIP_TRY(hipStreamWaitEvent(e->xstream, ev, 0));
+    if ((rc = slab_pack_on(e, e->xstream))) return rc;
+    HIP_TRY(hipEventRecord(e->evPacked, e->xstream));
+    e->stepPending = true;
+    return SPH_OK;
+}
+static int slab_step_join(SphEngine* e) {
+    HIP_TRY(hipEventRecord(e->evDone, e->xstream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->evDone, 0));                    // the next substep's grid build sees the received records
+    e->stepPending = false;
+    return SPH_OK;
+}
+int sph_slab_step_finish_local(SphEngine* e, SphEngine* lo, SphEngine* hi) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_finish_local without sph_slab_step_begin");
+    if ((e->hasLo != 0) != (lo != nullptr) || (e->hasHi != 0) != (hi != nullptr)) return fail(SPH_ERR_ARG, "neighbour engines do not match the slab's faces");
+    for (SphEngine* nb : {lo, hi})
+        if (nb && !nb->evPacked) return fail(SPH_ERR_STATE, "a neighbour engine has not begun its step");
+    const size_t bytes = ((size_t)e->faceCap + 1) * sizeof(SlabRec);
+    if (lo) {
+        if (lo->faceCap != e->faceCap) return fail(SPH_ERR_ARG, "face capacities differ");
+        HIP_TRY(hipStreamWaitEvent(e->xstream, lo->evPacked, 0));
+        HIP_TRY(hipMemcpyAsync(e->d_face[2], lo->d_face[1], bytes, hipMemcpyDeviceToDevice, e->xstream));    // its "send hi" is my "receive lo"
+    }
+    if (hi) {
+        if (hi->faceCap != e->faceCap) return fail(SPH_ERR_ARG, "face capacities differ");
+        HIP_TRY(hipStreamWaitEvent(e->xstream, hi->evPacked, 0));
+        HIP_TRY(hipMemcpyAsync(e->d_face[3], hi->d_face[0], bytes, hipMemcpyDeviceToDevice, e->xstream));
+    }
+    int rc;
+    if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap))) return rc;
+    if ((rc = slab_step_join(e))) return rc;
+    if (lo) lo->peerDone[1] = e->evDone;                                     // their next pack overwrites the face this engine has just read
+    if (hi) hi->peerDone[0] = e->evDone;
     return SPH_OK;
 }
 int sph_slab_status(SphEngine* e, uint32_t out[5]) {
@@ -1294,7 +1384,7 @@ int sph_comm_destroy(SphComm* c) {
 // One halo exchange of a substep: pack -> one grouped ncclSend / ncclRecv per z-neighbour (fixed-size messages: header
 // record + faceCap payload records) -> unpack, all enqueued on the engine's stream: no host synchronisation, and the
 // stream order makes the unpack wait for the receives and the next pack wait for the sends.
-int sph_slab_exchange(SphEngine* e, SphComm* c) {
+static int slab_check_comm(SphEngine* e, SphComm* c) {
     if (!e || !c) return fail(SPH_ERR_ARG, "null argument");
     if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
     // both directions: a rank that waits for a neighbour the neighbour does not know about would hang in ncclRecv
@@ -1321,29 +1411,54 @@ int sph_slab_exchange(SphEngine* e, SphComm* c) {
                         e->faceCap, agreed[0], ~agreed[1]);
         e->faceAgreedWith = c;
     }
-    if ((rc = sph_slab_pack_async(e))) return rc;
+    return SPH_OK;
+}
+// the grouped ncclSend / ncclRecv with the (at most two) z-neighbours of fixed-size messages (header record + faceCap payload records)
+static int slab_transfer_rccl(SphEngine* e, SphComm* c, hipStream_t st) {
     const size_t bytes = ((size_t)e->faceCap + 1) * sizeof(SlabRec);
     if (e->hasLo || e->hasHi) {
         NCCL_TRY(g_rccl.GroupStart());
         ncclResult_t r = ncclSuccess;
         if (e->hasLo) {
-            r = g_rccl.Send(e->d_face[0], bytes, ncclUint8, c->rank - 1, c->comm, e->stream);
-            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2], bytes, ncclUint8, c->rank - 1, c->comm, e->stream);
+            r = g_rccl.Send(e->d_face[0], bytes, ncclUint8, c->rank - 1, c->comm, st);
+            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2], bytes, ncclUint8, c->rank - 1, c->comm, st);
         }
         if (r == ncclSuccess && e->hasHi) {
-            r = g_rccl.Send(e->d_face[1], bytes, ncclUint8, c->rank + 1, c->comm, e->stream);
-            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[3], bytes, ncclUint8, c->rank + 1, c->comm, e->stream);
+            r = g_rccl.Send(e->d_face[1], bytes, ncclUint8, c->rank + 1, c->comm, st);
+            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[3], bytes, ncclUint8, c->rank + 1, c->comm, st);
         }
         ncclResult_t g = g_rccl.GroupEnd();
         if (r != ncclSuccess) return fail(SPH_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
         if (g != ncclSuccess) return fail(SPH_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(g));
     }
+    return SPH_OK;
+}
+// One halo exchange of a substep: pack -> one grouped ncclSend / ncclRecv per z-neighbour -> unpack, all enqueued on the
+// engine's stream: no host synchronisation, and the stream order makes the unpack wait for the receives and the next pack
+// wait for the sends.
+int sph_slab_exchange(SphEngine* e, SphComm* c) {
+    int rc;
+    if ((rc = slab_check_comm(e, c))) return rc;
+    if (e->stepPending) return fail(SPH_ERR_STATE, "a boundary-first step is pending: finish it with sph_slab_step_finish");
+    if ((rc = sph_slab_pack_async(e))) return rc;
+    if ((rc = slab_transfer_rccl(e, c, e->stream))) return rc;
     return sph_slab_unpack_async(e, e->d_face[2], e->d_face[3], e->faceCap);
+}
+// Second half of a boundary-first substep with RCCL as the transport: the transfer and the unpack follow the pack on the
+// exchange stream; the engine's stream (the interior of the SPH pass) only waits for them at its end.
+int sph_slab_step_finish(SphEngine* e, SphComm* c) {
+    int rc;
+    if ((rc = slab_check_comm(e, c))) return rc;
+    if (!e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_finish without sph_slab_step_begin");
+    if ((rc = slab_transfer_rccl(e, c, e->xstream))) return rc;
+    if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap))) return rc;
+    return slab_step_join(e);
 }
 
 int sph_sync(SphEngine* e) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->xstream) HIP_TRY(hipStreamSynchronize(e->xstream));
     return SPH_OK;
 }
 

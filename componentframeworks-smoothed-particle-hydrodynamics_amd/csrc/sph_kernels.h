@@ -707,13 +707,15 @@ __global__ __launch_bounds__(kBlock) void k_sph_ll(SimK k, StateIn in, StateOut 
 }
 
 // ======================= z-slab (multi-GPU) support ==========================================
-// 48-byte record that crosses ranks: a migrant (flags without F_HALO: the receiver owns it)
-// or a boundary-layer copy (F_HALO set: candidate only).
+// 64-byte record that crosses ranks: a migrant (flags without F_HALO: the receiver owns it)
+// or a boundary-layer copy (F_HALO set: candidate only).  acc travels too: a migrant's record of THIS substep
+// (the 80-byte contract includes acc) is complete on its new owner even though the new owner never computed it.
 struct SlabRec {
     float px, py, pz, vx, vy, vz, rho, prs, foam;
     uint32_t id, flags, pad;
+    float ax, ay, az, pad2;
 };
-static_assert(sizeof(SlabRec) == 48, "SlabRec is 48 bytes");
+static_assert(sizeof(SlabRec) == 64, "SlabRec is 64 bytes");
 
 __global__ __launch_bounds__(kBlock) void k_slab_import(const SphParticle* __restrict__ aos, const uint32_t* __restrict__ ids,
                                                         float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
@@ -750,7 +752,7 @@ __device__ __forceinline__ void slab_append(SlabRec* buf, uint32_t* counter, uin
 // counters[0] = records for the lower neighbour, counters[1] = for the upper neighbour.
 __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, int hasLo, int hasHi, float4* __restrict__ pos,
                                                       const float4* __restrict__ vel, const float2* __restrict__ rp,
-                                                      const float* __restrict__ foam, int nBound, SlabRec* __restrict__ sendLo,
+                                                      const float* __restrict__ foam, const float4* __restrict__ acc, int nBound, SlabRec* __restrict__ sendLo,
                                                       SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi,
                                                       uint32_t* __restrict__ counters, const uint32_t* __restrict__ cellStart, int layerCells) {
     const int gzLocal = z1 - z0 + 2;                    // the rank's layers plus one ghost layer each side (k holds the GLOBAL grid here)
@@ -761,16 +763,21 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
     // particle by more than one cell layer since (velocity cap, unchanged container).  Everything this pass acts on --
     // stale ghosts, face particles, migrants -- then entered that substep in one of the three lowest or three highest
     // local layers, i.e. sits in two slot ranges at the ends; blocks in between have nothing to do.
+    bool inEnds = true;
     if (cellStart && gzLocal > 6) {
         const int endLo = (int)cellStart[3 * layerCells], startHi = (int)cellStart[(gzLocal - 3) * layerCells];
         const int b0 = (int)(blockIdx.x * kBlock);
         if (b0 >= endLo && b0 + kBlock <= startHi) return;
+        // exactly the two ranges, slot by slot: the boundary-first substep (sph_slab_step_begin) runs this pass while the SPH
+        // pass is still writing the slots in between
+        inEnds = i < endLo || i >= startHi;
     }
     bool toLoBuf = false, toHiBuf = false;
     SlabRec r;
     r.px = r.py = r.pz = r.vx = r.vy = r.vz = r.rho = r.prs = r.foam = 0.0f; r.id = 0; r.flags = 0; r.pad = 0;
+    r.ax = r.ay = r.az = r.pad2 = 0.0f;
     uint32_t fLo = 0, fHi = 0;
-    if (i < n) {
+    if (i < n && inEnds) {
         const float4 P = pos[i];
         uint32_t flags = fbits(P.w);
         if (!(flags & F_DEAD)) {
@@ -783,6 +790,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
                 const float2 RP = rp[i];
                 r.px = P.x; r.py = P.y; r.pz = P.z; r.vx = V.x; r.vy = V.y; r.vz = V.z;
                 r.rho = RP.x; r.prs = RP.y; r.foam = foam[i]; r.id = fbits(V.w);
+                if (acc) { const float4 A = acc[i]; r.ax = A.x; r.ay = A.y; r.az = A.z; }
                 toLoBuf = hasLo && (goLo || cz == z0);
                 toHiBuf = hasHi && (goHi || cz == z1 - 1);
                 fLo = goLo ? flags : (flags | F_HALO);
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
 // Append received records behind the local slots.
 __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restrict__ recv, int nRecv, float4* __restrict__ pos,
                                                         float4* __restrict__ vel, float2* __restrict__ rp, float* __restrict__ foam,
-                                                        int dstBase) {
+                                                        float4* __restrict__ acc, int dstBase) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nRecv) return;
     const SlabRec r = recv[i];
@@ -810,6 +818,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
     vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
+    acc[d] = make_float4(r.ax, r.ay, r.az, 0.0f);
 }
 
 // ---- exchange without host round trips: the record count travels in a header record in front of the payload ----
@@ -820,8 +829,8 @@ __global__ void k_slab_headers(uint32_t* __restrict__ counters, SlabRec* __restr
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t nl = counters[0], nh = counters[1];
     if (nl > capLo || nh > capHi) atomicOr(&counters[4], 1u);
-    if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nl, capLo); h.flags = kSlabMagic; h.pad = nl; sendLo[0] = h; }
-    if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = 0.0f; h.id = min(nh, capHi); h.flags = kSlabMagic; h.pad = nh; sendHi[0] = h; }
+    if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = h.ax = h.ay = h.az = h.pad2 = 0.0f; h.id = min(nl, capLo); h.flags = kSlabMagic; h.pad = nl; sendLo[0] = h; }
+    if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = h.ax = h.ay = h.az = h.pad2 = 0.0f; h.id = min(nh, capHi); h.flags = kSlabMagic; h.pad = nh; sendHi[0] = h; }
     counters[5] = nl; counters[6] = nh;                 // what sph_slab_status reports
     counters[0] = 0u; counters[1] = 0u;                 // ready for the next k_slab_pack (no memset between substeps)
 }
@@ -835,7 +844,7 @@ __device__ __forceinline__ uint32_t slab_header_count(const SlabRec* __restrict_
 // direction's count when `afterOther` points at that header).
 __global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __restrict__ recv, const SlabRec* __restrict__ afterOther, uint32_t recvCap,
                                                             float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
-                                                            float* __restrict__ foam, uint32_t* __restrict__ counters, uint32_t slotCap) {
+                                                            float* __restrict__ foam, float4* __restrict__ acc, uint32_t* __restrict__ counters, uint32_t slotCap) {
     const uint32_t cnt = slab_header_count(recv, recvCap);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= cnt) return;
@@ -847,6 +856,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __res
     vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
+    acc[d] = make_float4(r.ax, r.ay, r.az, 0.0f);
 }
 // counters[4] bit 2: a received header was not a header (magic / count); bit 3: the SENDER had more records than its
 // message could carry (header.pad = its true count), i.e. the neighbour's overflow made visible on this rank too.

@@ -79,7 +79,8 @@ __device__ __forceinline__ void pair_xsph_other(const SimK& k, Own& o, const flo
 template <int MAXN, int UNROLL, int CAP, bool SMALLH>
 __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                                   const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n,
-                                                                  int dbg, unsigned long long* __restrict__ stats) {
+                                                                  int dbg, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ rangeLo,
+                                                                  const uint32_t* __restrict__ rangeHi) {
     constexpr int kB = 256;
     constexpr uint32_t kRowBytes = kB * 2;                 // one list row = one entry of every thread
     static_assert(kRowBytes == 512, "the cursor advance reads bit 9 of (sign >> 22)");
@@ -91,11 +92,15 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     // XCD-aware block mapping as in k_sph_list: blocks b and b + 8 share an XCD, each XCD walks one contiguous eighth of the LIVE slots.
-    const int bound = liveCount ? min(n, (int)*liveCount) : n;
-    const int nBlocks = (bound + kB - 1) / kB, perXcd = (nBlocks + 7) >> 3;
+    // A launch may cover only the slot range [*rangeLo, *rangeHi) (device-side bounds, nullptr = open end): a z-slab engine
+    // runs the slots next to its faces first, so that the halo exchange can start while the interior is still being computed.
+    const int boundAll = liveCount ? min(n, (int)*liveCount) : n;
+    const int first = rangeLo ? min((int)*rangeLo, boundAll) : 0;
+    const int bound = rangeHi ? min((int)*rangeHi, boundAll) : boundAll;
+    const int nBlocks = (max(bound - first, 0) + kB - 1) / kB, perXcd = (nBlocks + 7) >> 3;
     const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
     if (((int)blockIdx.x >> 3) >= perXcd || vb >= nBlocks) return;   // whole block, uniformly
-    const int sRaw = vb * kB + tid;
+    const int sRaw = first + vb * kB + tid;
     bool live = sRaw < bound;                              // every lane stays to the end (the staging is a wave-wide cooperation)
     const int s = live ? sRaw : max(bound - 1, 0);
     const float4 P = S.P(s), V = S.V(s), O = S.own[s];

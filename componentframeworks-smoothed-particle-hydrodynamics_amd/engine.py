@@ -90,10 +90,14 @@ ABI_SYMBOLS = (
     "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
     "sph_slab_alloc_faces", "sph_slab_face_buffer", "sph_slab_pack_async", "sph_slab_unpack_async", "sph_slab_status",
     "sph_comm_unique_id", "sph_comm_create", "sph_comm_destroy", "sph_slab_exchange",
+    "sph_slab_step_begin", "sph_slab_step_finish", "sph_slab_step_finish_local",
     "sph_river_default", "sph_generate_river_terrain", "sph_spawn_river_particles", "sph_set_river", "sph_get_river",
 )
-# sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_list, summed over launches
-STAMP_NAMES = ("slow_waves", "slow_targets", "list_entries", "window_candidates", "lanes", "overflow_targets", "far_targets", "waves_with_fallback")
+# sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_walk / k_sph_list, summed over launches:
+# [0] candidate rows walked from global memory (window too large; k_sph_walk), [1] targets on an exact fallback sweep,
+# [2] neighbour-list entries, [3] candidate rows (k_sph_walk), [4] lanes, [5] targets whose list overflowed, [6] targets that
+# left the list's slack, [7] waves with at least one fallback target
+STAMP_NAMES = ("rows_unstaged", "slow_targets", "list_entries", "rows", "lanes", "overflow_targets", "far_targets", "waves_with_fallback")
 
 
 class SphError(RuntimeError):
@@ -180,6 +184,9 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int]
     L.sph_comm_destroy.argtypes = [vp]
     L.sph_slab_exchange.argtypes = [vp, vp]
+    L.sph_slab_step_begin.argtypes = [vp, C.c_float]
+    L.sph_slab_step_finish.argtypes = [vp, vp]
+    L.sph_slab_step_finish_local.argtypes = [vp, vp, vp]
     L.sph_river_default.argtypes = [C.POINTER(SphRiver)]
     L.sph_generate_river_terrain.argtypes = [pp, C.c_int, C.POINTER(SphRiver), vp]
     L.sph_spawn_river_particles.argtypes = [pp, C.POINTER(SphRiver), vp, C.c_size_t, C.c_uint32, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]

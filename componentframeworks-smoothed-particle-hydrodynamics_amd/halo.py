@@ -7,7 +7,7 @@ interaction radius equals the cell size, and the SPH pass reads only the dispatc
 snapshot of its neighbours, so ONE exchange per substep suffices:
 
     pack      every rank classifies its particles by current position and emits, per z-neighbour,
-              one stream of 48-byte records: migrants (now owned by the neighbour) and copies of
+              one stream of 64-byte records: migrants (now owned by the neighbour) and copies of
               its boundary-layer particles (ghosts for the neighbour)
     exchange  with at most two neighbours.  Measured path: sph_slab_exchange of the C-ABI (grouped
               ncclSend/ncclRecv = RCCL over xGMI on the engine's stream, record counts in a header record,
@@ -29,7 +29,7 @@ import numpy as np
 from . import engine as _eng
 from . import synthetic as _syn
 
-REC_WORDS = 12          # 48-byte exchange record
+REC_WORDS = 16          # 64-byte exchange record: pos3 vel3 rho prs foam id flags pad acc3 pad
 OUT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("vel", "<f4", (3,)), ("acc", "<f4", (3,)), ("density", "<f4"),
                       ("pressure", "<f4"), ("padA", "<f4"), ("id", "<u4"), ("flags", "<u4"), ("pad", "<u4", (2,))])
 assert OUT_DTYPE.itemsize == 64
@@ -94,6 +94,17 @@ class HipSlabEngine:
     def exchange(self, comm: "RcclComm"):
         """pack -> grouped ncclSend/ncclRecv with the z-neighbours -> unpack, on the engine's stream (sph_slab_exchange)."""
         _eng._check(self._L.sph_slab_exchange(self._h, comm._h))
+
+    # -- boundary-first substep: the exchange of the next substep beside the interior of the SPH pass ----------
+    def step_begin(self, dt=-1.0):
+        _eng._check(self._L.sph_set_params(self._h, C.byref(self._p)))
+        _eng._check(self._L.sph_slab_step_begin(self._h, dt))
+
+    def step_finish(self, comm: "RcclComm"):
+        _eng._check(self._L.sph_slab_step_finish(self._h, comm._h))
+
+    def step_finish_local(self, lo: "HipSlabEngine | None", hi: "HipSlabEngine | None"):
+        _eng._check(self._L.sph_slab_step_finish_local(self._h, lo._h if lo is not None else None, hi._h if hi is not None else None))
 
     def sync(self):
         _eng._check(self._L.sph_sync(self._h))
@@ -293,8 +304,17 @@ class SlabSimulation:
         return sim
 
     # -- the substep -------------------------------------------------------------------------------
+    overlap = True       # RCCL path: boundary-first substeps (sph_slab_step_*), the exchange hidden behind the interior of the SPH pass
+
     def DispatchCompute(self, overrideDt: float = -1.0):
         if isinstance(self.exchange, RcclComm):          # the measured path: everything behind the C-ABI, no host round trip
+            if self.overlap:
+                if not getattr(self, "_primed", False):  # the first substep's halos; every later exchange rides inside a step
+                    self.engine.exchange(self.exchange)
+                    self._primed = True
+                self.engine.step_begin(overrideDt)
+                self.engine.step_finish(self.exchange)
+                return
             self.engine.exchange(self.exchange)
             self.engine.dispatch(overrideDt)
             return
@@ -354,7 +374,37 @@ class SlabGroup:
             s.engine.alloc_faces(face_capacity)
         self._async_cap = int(face_capacity)
 
+    def enable_overlap(self, face_capacity: int):
+        """Boundary-first substeps (sph_slab_step_begin / sph_slab_step_finish_local): every engine packs on its second stream as
+        soon as the slots next to its faces are computed, copies its neighbours' send faces device to device and unpacks, all
+        beside the interior of its SPH pass -- the schedule sph_slab_step_finish runs with RCCL in place of the copies."""
+        self.enable_async(face_capacity)
+        self._overlap = True
+        self._primed = False
+
+    def _exchange_async(self):
+        for s in self.sims:
+            s.engine.pack_async()
+        for s in self.sims:                       # the engines run on their own streams: a pack must have finished
+            s.engine.sync()                       # before the neighbour reads it (RCCL gives that order on real ranks)
+        for r, s in enumerate(self.sims):
+            lo = self.sims[r - 1].engine.face_ptr(1) if r > 0 else None                 # lower neighbour's "send hi"
+            hi = self.sims[r + 1].engine.face_ptr(0) if r < len(self.sims) - 1 else None  # upper neighbour's "send lo"
+            s.engine.unpack_async(lo, hi, self._async_cap)
+        for s in self.sims:
+            s.engine.sync()
+
     def DispatchCompute(self, overrideDt: float = -1.0):
+        if getattr(self, "_overlap", False):
+            if not self._primed:
+                self._exchange_async()
+                self._primed = True
+            for s in self.sims:                   # every begin before any finish: a finish waits for the neighbours' packs
+                s.engine.step_begin(overrideDt)
+            for r, s in enumerate(self.sims):
+                s.engine.step_finish_local(self.sims[r - 1].engine if r > 0 else None,
+                                           self.sims[r + 1].engine if r < len(self.sims) - 1 else None)
+            return
         if getattr(self, "_async_cap", 0):
             for s in self.sims:
                 s.engine.pack_async()

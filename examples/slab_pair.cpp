@@ -1,8 +1,8 @@
 // slab_pair.cpp -- two z-slab engines driven through the C-ABI only (include/sph_abi.h), the way a C++ host such as
-// Scene0p's owner would drive one rank per GPU: pack -> exchange -> unpack -> DispatchCompute, with the record counts
-// staying on the device (no host round trip per substep).  On ONE GPU the two "ranks" live in this process and hand each
-// other their send buffers directly (sph_slab_pack_async / sph_slab_unpack_async); with one process per GPU the same two
-// calls are replaced by sph_slab_exchange(engine, comm), which puts a grouped ncclSend/ncclRecv between them.
+// Scene0p's owner would drive one rank per GPU, on the boundary-first schedule: sph_slab_step_begin (DispatchCompute with the
+// slots next to the faces first + the pack of the next exchange on a second stream) and sph_slab_step_finish_local (copy of the
+// neighbour's send face, unpack), record counts staying on the device, no host synchronisation per substep.  On ONE GPU the two
+// "ranks" live in this process; with one process per GPU sph_slab_step_finish(engine, comm) puts RCCL in place of the copy.
 // The result is compared with a single engine over the whole domain: bit for bit.
 //
 //   g++ -std=c++17 -I include examples/slab_pair.cpp -L <pkg dir> -lsph_hip -o slab_pair
@@ -54,21 +54,27 @@ int main(int argc, char** argv) {
     CHECK(sph_slab_face_buffer(slab[0], 1, &sendHi0));
     CHECK(sph_slab_face_buffer(slab[1], 0, &sendLo1));
     const float dir[3] = {0.f, 1.f, 0.f};
+    // Prime: the halo records of the FIRST substep, by a plain exchange.  The two engines run on their own streams: the hand-off
+    // needs each pack finished before the other side reads it.
+    for (auto* e : slab) CHECK(sph_slab_pack_async(e));
+    for (auto* e : slab) CHECK(sph_sync(e));
+    CHECK(sph_slab_unpack_async(slab[0], nullptr, sendLo1, faceCap));
+    CHECK(sph_slab_unpack_async(slab[1], sendHi0, nullptr, faceCap));
+    for (auto* e : slab) CHECK(sph_sync(e));
     for (int s = 0; s < steps; ++s) {
         if (s % 16 == 0) {                                   // Scene0p.h:144-147 continuous wave
             for (auto* e : slab) CHECK(sph_apply_wave_impulse(e, 1.5f, 3.0f, 0.064f * (float)s, dir, -3.4e38f, 3.4e38f));
             CHECK(sph_apply_wave_impulse(one, 1.5f, 3.0f, 0.064f * (float)s, dir, -3.4e38f, 3.4e38f));
         }
-        // the two engines run on their own streams: the hand-off below needs each pack finished before the other side
-        // reads it (with sph_slab_exchange the RCCL calls on the engine's stream give that order)
-        for (auto* e : slab) CHECK(sph_slab_pack_async(e));
-        for (auto* e : slab) CHECK(sph_sync(e));
-        CHECK(sph_slab_unpack_async(slab[0], nullptr, sendLo1, faceCap));
-        CHECK(sph_slab_unpack_async(slab[1], sendHi0, nullptr, faceCap));
-        for (auto* e : slab) CHECK(sph_sync(e));
-        for (auto* e : slab) CHECK(sph_dispatch(e, -1.0f));
+        // Boundary-first substeps: each engine computes the slots next to its faces first, packs on its second stream, copies the
+        // neighbour's send face device to device and unpacks -- beside the interior of its SPH pass, no host synchronisation.
+        // With one process per GPU the second call is sph_slab_step_finish(engine, comm): RCCL in place of the copy.
+        for (auto* e : slab) CHECK(sph_slab_step_begin(e, -1.0f));
+        CHECK(sph_slab_step_finish_local(slab[0], nullptr, slab[1]));
+        CHECK(sph_slab_step_finish_local(slab[1], slab[0], nullptr));
         CHECK(sph_dispatch(one, -1.0f));
     }
+    for (auto* e : slab) CHECK(sph_sync(e));
     std::vector<SphParticle> want(n);
     CHECK(sph_download_particles(one, want.data(), n));
     size_t got = 0, bad = 0, moved = 0;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 1
+#define SPH_ABI_VERSION 2   /* 2: sph_slab_step_*, header validation of received halo messages, SPH_OPT_NEIGHBOR_KERNEL 3 (default), records on demand by default */
 
 enum {
     SPH_OK = 0,
@@ -257,9 +257,10 @@ int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset);
 /* ---- multi-GPU: z-slab decomposition (no reference counterpart) ------------
  * One engine per rank owns the global cell layers [z0, z1) of ComputeGridExtents' grid plus one
  * read-only ghost layer per side.  Per substep the host calls pack -> (exchange) -> unpack ->
- * sph_dispatch.  Records crossing ranks are 48 bytes: float px,py,pz,vx,vy,vz,rho,prs,foam;
- * uint32 id, flags, pad.  Buffers passed to pack/unpack are DEVICE pointers. */
-#define SPH_SLAB_REC_BYTES 48
+ * sph_dispatch.  Records crossing ranks are 64 bytes: float px,py,pz,vx,vy,vz,rho,prs,foam;
+ * uint32 id, flags, pad; float ax,ay,az,pad (acc travels so that a migrant's 80-byte record is complete
+ * on its new owner).  Buffers passed to pack/unpack are DEVICE pointers. */
+#define SPH_SLAB_REC_BYTES 64
 #define SPH_SLAB_OUT_BYTES 64
 /* `ids` are global particle ids (they fix the summation order, so results do not depend on the
  * decomposition); `capacity` bounds owned + ghost + migrated-in slots. */
@@ -297,6 +298,22 @@ int sph_comm_unique_id(void* out128);
 int sph_comm_create(SphComm** out, const void* id128, int rank, int world);
 int sph_comm_destroy(SphComm* comm);
 int sph_slab_exchange(SphEngine* e, SphComm* comm);
+/* ---- boundary-first substep: the exchange hidden behind the interior of the SPH pass -----------------------------
+ * sph_slab_step_begin = sph_dispatch, except that the SPH pass runs the slot ranges next to the slab's faces first (the
+ * three lowest / three highest local cell layers: everything the next pack can touch, since the velocity cap bounds a
+ * substep's move to one layer), and then, on a second stream of the engine, the pack of the exchange that prepares the
+ * NEXT substep -- while the interior slots are still being computed on the engine's stream.  The second half moves the
+ * faces and unpacks, still on the second stream; the engine's stream waits for it only at its end:
+ *   sph_slab_step_finish(engine, comm)            one process per GPU: grouped ncclSend / ncclRecv (RCCL over xGMI)
+ *   sph_slab_step_finish_local(engine, lo, hi)    several slab engines in ONE process: device-to-device copies of the
+ *                                                 neighbours' send faces (call every engine's _begin before any _finish_local)
+ * Both transports run the same stream / event schedule.  The state a step leaves behind already holds the halo records of
+ * the next substep, so a run is: one plain exchange (sph_slab_exchange, or pack_async / unpack_async) to prime it, then
+ * only steps; impulses go between steps as usual (they act on the halo copies as on their owners).  Members that move the
+ * grid must not change between two steps.  Results are bit-identical to exchange + sph_dispatch. */
+int sph_slab_step_begin(SphEngine* e, float overrideDt);
+int sph_slab_step_finish(SphEngine* e, SphComm* comm);
+int sph_slab_step_finish_local(SphEngine* e, SphEngine* lo, SphEngine* hi);
 
 /* ---- measurement ----------------------------------------------------------------- */
 enum {

@@ -30,7 +30,7 @@ class OracleSlabEngine:
         return np.clip(np.floor(q), 0, g.dims[2] - 1).astype(np.int64)
 
     def _records(self, idx, flags):
-        r = np.zeros((len(idx), 12), np.float32)
+        r = np.zeros((len(idx), 16), np.float32)
         r[:, 0:3] = self.pos[idx]
         r[:, 3:6] = self.vel[idx]
         r[:, 6] = self.rho[idx]
@@ -38,6 +38,7 @@ class OracleSlabEngine:
         r[:, 8] = self.foam[idx]
         r[:, 9] = self.id[idx].view(np.float32)
         r[:, 10] = flags.astype(np.uint32).view(np.float32)
+        r[:, 12:15] = self.acc[idx]
         return r
 
     def pack(self, send_lo, send_hi):
@@ -81,7 +82,7 @@ class OracleSlabEngine:
         r = np.concatenate(parts).astype(np.float32)
         self.pos = np.concatenate([self.pos, r[:, 0:3]])
         self.vel = np.concatenate([self.vel, r[:, 3:6]])
-        self.acc = np.concatenate([self.acc, np.zeros((len(r), 3), np.float32)])
+        self.acc = np.concatenate([self.acc, r[:, 12:15]])
         self.rho = np.concatenate([self.rho, r[:, 6]])
         self.prs = np.concatenate([self.prs, r[:, 7]])
         self.foam = np.concatenate([self.foam, r[:, 8]])

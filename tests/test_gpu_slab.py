@@ -98,6 +98,60 @@ def test_async_exchange_matches_single_engine(pkg, oracle, world):
     single.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_boundary_first_steps_match_single_engine(pkg, oracle, world):
+    """sph_slab_step_begin / sph_slab_step_finish_local: the SPH pass runs the slots next to the faces first, the exchange
+    of the NEXT substep (pack -> device-to-device copy of the neighbours' send faces -> unpack) runs on each engine's second
+    stream beside the interior of the pass.  Same bits as the single engine and the oracle, impulses between the steps
+    included (they reach the halo copies that are already in place); no overflow, and records did cross the faces."""
+    import torch
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, world)
+    grp.enable_overlap(8192)
+    single = pkg.SPHFluidGPU.from_particles(P, sp)
+    want = P
+    for s in range(12):
+        if s % 3 == 0:
+            args = (1.5, 3.0, 0.1 * s, (0.2, 1.0, 0.4), -2.0, 2.0)
+            grp.ApplyWaveImpulse(*args)
+            single.ApplyWaveImpulse(*args)
+            want = oracle.wave_impulse(want, *args)
+        grp.DispatchCompute()
+        single.DispatchCompute()
+        want = oracle.substep(want, op)
+    torch.cuda.synchronize()
+    got = halo.merge_into_records(P, grp.download())
+    assert_records_equal(got, single.download(), f"{world} slabs (boundary-first steps) vs one engine")
+    assert_records_equal(got, want, f"{world} slabs (boundary-first steps) vs oracle")
+    st = [s.engine.status() for s in grp.sims]
+    assert all(x[4] == 0 for x in st) and sum(x[0] + x[1] for x in st) > 0
+    single.close()
+
+
+def test_boundary_first_steps_with_a_container_change(pkg, oracle):
+    """As test_container_change_under_the_reduced_face_scan, on the boundary-first schedule: after the container changed under
+    the fluid the SPH pass is not split and the pack scans every slot, one substep long."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, 3)
+    grp.enable_overlap(8192)
+    single = pkg.SPHFluidGPU.from_particles(P, sp)
+    want = P
+    for s in range(9):
+        if s == 4:
+            sp.param_shapeType = 1                        # sphere of the same extent: same grid, corner particles jump inwards
+            single.param_shapeType = 1                    # (the slab engines share `sp`; the single engine has its own copy)
+            op.shapeType = 1
+        grp.DispatchCompute()
+        single.DispatchCompute()
+        want = oracle.substep(want, op)
+    got = halo.merge_into_records(P, grp.download())
+    assert_records_equal(got, single.download(), "3 slabs (boundary-first steps, container change) vs one engine")
+    assert_records_equal(got, want, "3 slabs (boundary-first steps, container change) vs oracle")
+    single.close()
+
+
 def test_container_change_under_the_reduced_face_scan(pkg, oracle):
     """k_slab_pack looks only at the two ends of the (z-major sorted) slot range while nothing can have moved a particle
     by more than one layer.  A container that changes under the fluid can: box -> sphere of the same extent (same grid)
