@@ -207,19 +207,23 @@ __global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, 
     if (d == 0 && liveOut) *liveOut = cellStart[numCells];
     if (d >= n || (uint32_t)d >= cellStart[numCells]) return;   // live particles only (cellStart[numCells] <= n)
     uint2 me = tmp[d];
+    // everything that depends only on the source index is requested NOW, beside the cell lookups below (one level of
+    // dependent memory latency less than gathering after the rank is known)
+    float4 P = make_float4(0.0f, 0.0f, 0.0f, 0.0f), V = P;
+    float2 RP = make_float2(0.0f, 0.0f);
+    float F = 0.0f;
+    if (COPY) { P = pos[me.y]; V = vel[me.y]; RP = rp[me.y]; F = foam[me.y]; }
     uint32_t c = cellOf[me.y];
     uint32_t s = cellStart[c], e = cellStart[c + 1];
     uint32_t rank = 0;
     for (uint32_t q = s; q < e; ++q) rank += (tmp[q].x < me.x) ? 1u : 0u;
     order[s + rank] = me.y;
     if (COPY) {
-        const float4 P = pos[me.y], V = vel[me.y];
-        const float2 RP = rp[me.y];
         pv[2u * (s + rank)] = make_float4(P.x, P.y, P.z, RP.x > 0.0f ? 1.0f / RP.x : 0.0f);
         pv[2u * (s + rank) + 1u] = make_float4(V.x, V.y, V.z, RP.y);
         const uint32_t cxy = c % (uint32_t)(gx * gy);
         const uint32_t cellBits = (cxy % (uint32_t)gx) | ((cxy / (uint32_t)gx) << 10) | ((c / (uint32_t)(gx * gy)) << 20);   // dims <= 1024 (validate_params)
-        own[s + rank] = make_float4(bitsf(cellBits), foam[me.y], P.w, V.w);
+        own[s + rank] = make_float4(bitsf(cellBits), F, P.w, V.w);
     }
 }
 
