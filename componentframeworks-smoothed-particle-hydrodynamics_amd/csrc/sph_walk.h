@@ -32,7 +32,7 @@ namespace sph {
 #define SPH_WALK_WAVES 5     // __launch_bounds__ minimum waves per SIMD
 #endif
 #ifndef SPH_WALK_EPS
-#define SPH_WALK_EPS 0.06f   // slack of the list around the predicted position, in units of h
+#define SPH_WALK_EPS 0.04f   // slack of the list around the predicted position, in units of h (0.03 / 0.04 / 0.06 / 0.08: 442 / 441 / 451 / 463 us)
 #endif
 
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
