@@ -285,7 +285,15 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
             if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
             const int rowBase = (nz * k.gy + ny) * k.gx;
             const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
-            for (uint32_t q = a; q < b; ++q) f(S.P(q), S.V(q), (int32_t)((int)q != s ? -1 : 0));
+            // (a candidate outside h of every lane that is here adds +-0 everywhere: the wave skips its pair arithmetic)
+            auto within = [&](const float4& J) { const float dx = o.px - J.x, dy = o.py - J.y, dz = o.pz - J.z; return dot3(dx, dy, dz, dx, dy, dz) < k.h2; };
+            uint32_t q = a;
+            for (; q + 2u <= b; q += 2u) {                    // two candidates' loads in flight (in compressed fluid they are broadcasts: the wave's targets share their candidates)
+                const float4 J0 = S.P(q), V0 = S.V(q), J1 = S.P(q + 1u), V1 = S.V(q + 1u);
+                if (__any(within(J0))) f(J0, V0, (int32_t)((int)q != s ? -1 : 0));
+                if (__any(within(J1))) f(J1, V1, (int32_t)((int)(q + 1u) != s ? -1 : 0));
+            }
+            if (q < b) { const float4 J = S.P(q); if (__any(within(J))) f(J, S.V(q), (int32_t)((int)q != s ? -1 : 0)); }
         }
     };
     auto force_at = [&](const float4& J, const float4& JV) { pair_force_other(k, o, J, JV); };
