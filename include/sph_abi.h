@@ -122,14 +122,14 @@ typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHF
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
 enum {
-    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 2 = k_sph_list (default: one target per lane, LDS-staged candidate rows, neighbour lists), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 3 = k_sph_walk (default: one target per lane, LDS-staged candidate rows, neighbour lists walked per lane over 32-byte records), 2 = k_sph_list (round 2's form of the same plan), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 1 = lazy (default): the substep keeps its state in the engine's own arrays and the 80-byte records are brought up to date by sph_device_particles() / sph_download_particles() / sph_pack_render_buffer(), i.e. once per rendered frame instead of once per substep (the scattered 52-byte update of every record costs about 13 % of the SPH pass); 0 = eager: the SPH pass also updates the records, they are current after every dispatch. Same values either way. */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
     SPH_OPT_GRAPH_LAUNCHES = 6,  /* read-only: number of graph replays so far */
     SPH_OPT_TIMING = 4,          /* hipEvents around kernels for sph_kernel_times(): 1 = every kernel, 2 = only the SPH pass */
     /* test / tuning hooks */
-    SPH_OPT_DEBUG = 100          /* test hooks of k_sph_list -- bit 0: treat every neighbour list as overflowed, bit 1: treat every target as
+    SPH_OPT_DEBUG = 100          /* test hooks of k_sph_walk / k_sph_list -- bit 0: treat every neighbour list as overflowed, bit 1: treat every target as
                                     outside the list's slack (sweep-3 fallback), bit 2: treat every window as overflowed (whole wave falls
                                     back), bit 3: count fallbacks / list entries / staged candidates for sph_debug_counters */
 };
@@ -249,9 +249,11 @@ int sph_initial_particles(const SphEngine* e, SphParticle* host, size_t n);
  * particleCell[n] (binding 3) in the reference's cell indexing. Synchronises. */
 int sph_download_grid(SphEngine* e, int32_t* cellCount, size_t nCells, int32_t* particleCell, size_t n);
 int sph_sync(SphEngine* e);
-/* Diagnostic counters of k_sph_list (SPH_OPT_DEBUG bit 3), summed over launches since the last reset:
- * [0] waves that fell back as a whole, [1] targets recomputed by the exact fallback, [2] neighbour-list entries,
- * [3] candidates staged in LDS, [4] lanes (two targets each).  Never used on a timed path. */
+/* Diagnostic counters of the list passes k_sph_walk / k_sph_list (SPH_OPT_DEBUG bit 3), summed over launches since the last
+ * reset, 8 slots: [0] candidate rows walked from global memory because the wave's window did not fit (k_sph_walk only),
+ * [1] targets recomputed by an exact fallback sweep, [2] neighbour-list entries, [3] candidate rows (k_sph_walk only),
+ * [4] lanes (one target each), [5] targets whose list overflowed, [6] targets that left the list's slack (sweep-3
+ * fallback), [7] waves with at least one fallback target.  Never used on a timed path. */
 int sph_debug_counters(SphEngine* e, uint64_t* out, int count, int reset);
 
 /* ---- multi-GPU: z-slab decomposition (no reference counterpart) ------------

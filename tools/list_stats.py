@@ -26,7 +26,7 @@ for s in range(steps):
     c = f.debug_counters(reset=True)
     lanes = max(c["lanes"], 1)
     row = {"substep": s, "fallback_targets": c["slow_targets"], "overflow": c["overflow_targets"], "far": c["far_targets"],
-           "waves_with_fallback": c["waves_with_fallback"], "waves": lanes // 64, "rows_unstaged": c["slow_waves"], "rows": c["window_candidates"], "entries_per_lane": round(c["list_entries"] / lanes, 2)}
+           "waves_with_fallback": c["waves_with_fallback"], "waves": lanes // 64, "rows_unstaged": c["rows_unstaged"], "rows": c["rows"], "entries_per_lane": round(c["list_entries"] / lanes, 2)}
     if g is not None:
         g.DispatchCompute()
         a, b = f.download(), g.download()
