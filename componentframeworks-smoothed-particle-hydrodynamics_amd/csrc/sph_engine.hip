@@ -1381,6 +1381,44 @@ int sph_comm_destroy(SphComm* c) {
     delete c;
     return SPH_OK;
 }
+// Health check of the transport on THIS rank alone: one grouped ncclSend + ncclRecv of `bytes` bytes from the rank to
+// itself (RCCL serves a self send / recv with a device copy), issued the way slab_transfer_rccl issues the face messages
+// (ncclUint8 counts, a non-blocking stream that is not the null stream), then compared word for word on the host.
+// It is the only way to run ncclSend / ncclRecv on a box with one GPU (RCCL refuses two ranks on one device).
+int sph_comm_selftest(SphComm* c, uint64_t bytes) {
+    if (!c || !c->comm) return fail(SPH_ERR_ARG, "null communicator");
+    if (bytes == 0 || bytes > (1ull << 30) || (bytes & 3ull)) return fail(SPH_ERR_ARG, "bytes must be a multiple of 4 in (0, 2^30]");
+    const size_t words = (size_t)(bytes / 4);
+    uint32_t *src = nullptr, *dst = nullptr;
+    hipStream_t st = nullptr;
+    int rc = SPH_OK;
+    std::vector<uint32_t> host(words);
+    auto cleanup = [&]() { if (st) (void)hipStreamDestroy(st); if (src) (void)hipFree(src); if (dst) (void)hipFree(dst); };
+    if ((rc = dev_alloc(&src, words)) || (rc = dev_alloc(&dst, words))) { cleanup(); return rc; }
+    hipError_t er = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    for (size_t i = 0; i < words; ++i) host[i] = (uint32_t)i * 2654435761u + 12345u;
+    if (er == hipSuccess) er = hipMemcpyAsync(src, host.data(), bytes, hipMemcpyHostToDevice, st);
+    if (er == hipSuccess) er = hipMemsetAsync(dst, 0, bytes, st);
+    if (er != hipSuccess) { cleanup(); return fail(SPH_ERR_HIP, "self-test setup failed: %s", hipGetErrorString(er)); }
+    ncclResult_t g0 = g_rccl.GroupStart();
+    ncclResult_t r = g0;
+    if (r == ncclSuccess) r = g_rccl.Send(src, (size_t)bytes, ncclUint8, c->rank, c->comm, st);
+    if (r == ncclSuccess) r = g_rccl.Recv(dst, (size_t)bytes, ncclUint8, c->rank, c->comm, st);
+    ncclResult_t g1 = g0 == ncclSuccess ? g_rccl.GroupEnd() : g0;
+    if (r != ncclSuccess || g1 != ncclSuccess) {
+        (void)hipStreamSynchronize(st);
+        cleanup();
+        return fail(SPH_ERR_HIP, "self send / recv failed: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : g1));
+    }
+    std::vector<uint32_t> back(words);
+    er = hipMemcpyAsync(back.data(), dst, bytes, hipMemcpyDeviceToHost, st);
+    if (er == hipSuccess) er = hipStreamSynchronize(st);
+    cleanup();
+    if (er != hipSuccess) return fail(SPH_ERR_HIP, "self-test copy back failed: %s", hipGetErrorString(er));
+    for (size_t i = 0; i < words; ++i)
+        if (back[i] != host[i]) return fail(SPH_ERR_HIP, "self send / recv delivered wrong data at word %zu of %zu", i, words);
+    return SPH_OK;
+}
 // One halo exchange of a substep: pack -> one grouped ncclSend / ncclRecv per z-neighbour (fixed-size messages: header
 // record + faceCap payload records) -> unpack, all enqueued on the engine's stream: no host synchronisation, and the
 // stream order makes the unpack wait for the receives and the next pack wait for the sends.

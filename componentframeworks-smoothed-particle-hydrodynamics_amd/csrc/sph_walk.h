@@ -12,7 +12,8 @@
 //     ball, and the list cursor advances by (bits(s) >> 22) & 512;
 //   * the particle itself is left out of the list when it is built (sweeps 2 / 3 skip it by contract), so the walks need no
 //     per-entry validity mask; they are per-lane loops (no rounding of the list length to a group size), entries decode to
-//     byte offsets with two fast ops, and the gathers are bounds-checked buffer loads that are issued one entry ahead.
+//     byte offsets with two fast ops, and the gathers are bounds-checked buffer loads, issued two entries ahead and only for
+//     entries that exist (the pass is as much bound by the cache lines its gathers touch in L1 as by vector issue).
 #pragma once
 #include "sph_pass.h"
 

@@ -89,7 +89,7 @@ ABI_SYMBOLS = (
     "sph_debug_counters", "sph_apply_vortex_impulse", "sph_apply_attractor_impulse", "sph_set_stencil_targets",
     "sph_apply_stencil_attract", "sph_apply_curl_flow", "sph_fountain_default", "sph_set_fountain", "sph_get_fountain", "sph_create_slab", "sph_slab_pack", "sph_slab_unpack", "sph_slab_download",
     "sph_slab_alloc_faces", "sph_slab_face_buffer", "sph_slab_pack_async", "sph_slab_unpack_async", "sph_slab_status",
-    "sph_comm_unique_id", "sph_comm_create", "sph_comm_destroy", "sph_slab_exchange",
+    "sph_comm_unique_id", "sph_comm_create", "sph_comm_destroy", "sph_comm_selftest", "sph_slab_exchange",
     "sph_slab_step_begin", "sph_slab_step_finish", "sph_slab_step_finish_local",
     "sph_river_default", "sph_generate_river_terrain", "sph_spawn_river_particles", "sph_set_river", "sph_get_river",
 )
@@ -183,6 +183,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_comm_unique_id.argtypes = [vp]
     L.sph_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int]
     L.sph_comm_destroy.argtypes = [vp]
+    L.sph_comm_selftest.argtypes = [vp, C.c_uint64]
     L.sph_slab_exchange.argtypes = [vp, vp]
     L.sph_slab_step_begin.argtypes = [vp, C.c_float]
     L.sph_slab_step_finish.argtypes = [vp, vp]

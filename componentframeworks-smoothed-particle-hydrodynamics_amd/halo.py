@@ -163,6 +163,10 @@ class RcclComm:
         _eng._check(self._L.sph_comm_create(C.byref(self._h), idb, rank, world))
         self.rank, self.world = rank, world
 
+    def selftest(self, nbytes: int = 1 << 20):
+        """One grouped ncclSend + ncclRecv of `nbytes` from this rank to itself, checked on the host (sph_comm_selftest)."""
+        _eng._check(self._L.sph_comm_selftest(self._h, int(nbytes)))
+
     def close(self):
         if self._h:
             self._L.sph_comm_destroy(self._h)

@@ -299,6 +299,10 @@ int sph_slab_status(SphEngine* e, uint32_t out[5]);
 int sph_comm_unique_id(void* out128);
 int sph_comm_create(SphComm** out, const void* id128, int rank, int world);
 int sph_comm_destroy(SphComm* comm);
+/* Health check of the transport on this rank alone: one grouped ncclSend + ncclRecv of `bytes` bytes (a multiple of 4, at
+ * most 2^30) from the rank to itself on a non-blocking stream, compared on the host.  Synchronises.  (The only way to
+ * execute ncclSend / ncclRecv on a one-GPU box: RCCL refuses two ranks on one device.) */
+int sph_comm_selftest(SphComm* comm, uint64_t bytes);
 int sph_slab_exchange(SphEngine* e, SphComm* comm);
 /* ---- boundary-first substep: the exchange hidden behind the interior of the SPH pass -----------------------------
  * sph_slab_step_begin = sph_dispatch, except that the SPH pass runs the slot ranges next to the slab's faces first (the

@@ -322,3 +322,44 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["slab_status"]["overflow_on_any_rank"] is False
+
+
+_SELFTEST_CHILD = r"""
+import importlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+# as bench.py does at N > 1: torch's own RCCL process group first, then the engine's communicator beside it
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+halo = importlib.import_module(sys.argv[2] + ".halo")
+obj = [None]
+def bcast(b):
+    obj[0] = b
+    dist.broadcast_object_list(obj, src=0)
+    return obj[0]
+comm = halo.RcclComm(0, 1, bcast)
+for nbytes in (64, 1 << 20, (209716 + 1) * 64):          # the last: one face message of the weak-scaling slab (1.6 layers of 256 x 256 cells)
+    comm.selftest(nbytes)
+comm.close()
+dist.destroy_process_group()
+print("SELFTEST OK")
+"""
+
+
+def test_rccl_send_recv_to_self_in_a_child_process(tmp_path):
+    """ncclSend / ncclRecv through the engine's dlopen'd RCCL, executed on this one GPU: a communicator of one rank sends to
+    itself (sph_comm_selftest: grouped send + recv of uint8 counts on a non-blocking stream, compared on the host), beside a
+    torch.distributed RCCL process group as in bench.py's N > 1 path.  In a child process with a timeout, so that a transport
+    that hangs fails this test instead of stopping the run."""
+    import subprocess
+    script = tmp_path / "selftest_child.py"
+    script.write_text(_SELFTEST_CHILD)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script), ROOT, PKG_NAME], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0 and "SELFTEST OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
