@@ -522,12 +522,22 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
 namespace {
 using namespace sph;
 
+// What the unpack kernels need to tell whether a received particle respects the exchange's one-layer assumption.
+SlabGeom slab_geom(SphEngine* e) {
+    sph::compute_grid_extents(e->params, e->grid);
+    SlabGeom g;
+    g.gminz = e->grid.gridMin[2]; g.cellSize = e->grid.cellSize; g.gzGlobal = e->grid.dims[2];
+    g.z0 = e->z0; g.z1 = e->z1; g.hasLo = e->hasLo; g.hasHi = e->hasHi;
+    return g;
+}
+
 // Device-side error flags of the exchange (slabCnt[4]) as a status: every entry point that synchronises anyway reports them.
 int slab_flags_error(const SphEngine* e, uint32_t flags, uint32_t nLo, uint32_t nHi) {
     if (flags & 1u) return fail(SPH_ERR_CAPACITY, "halo send buffer overflowed (%u / %u records for a capacity of %u)", nLo, nHi, e->faceCap);
     if (flags & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
     if (flags & 4u) return fail(SPH_ERR_HIP, "a received halo message did not start with a valid header (magic / count): failed or garbled receive");
     if (flags & 8u) return fail(SPH_ERR_CAPACITY, "a neighbour rank had more halo records than its message could carry (face capacity %u)", e->faceCap);
+    if (flags & 16u) return fail(SPH_ERR_STATE, "a particle crossed more than one cell layer in z within one substep (placed outside the container, or a container that moved by cells): the slab decomposition no longer equals the single-domain run");
     return SPH_OK;
 }
 
@@ -1124,11 +1134,12 @@ int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* 
     if ((nLo && !recvLo) || (nHi && !recvHi)) return fail(SPH_ERR_ARG, "missing receive buffer");
     if (e->nSlots + nLo + nHi > e->cap) return fail(SPH_ERR_CAPACITY, "slab capacity %zu < %zu slots", e->cap, e->nSlots + nLo + nHi);
     const int c = e->cur;
+    const SlabGeom geom = slab_geom(e);
     if (nLo) hipLaunchKernelGGL(k_slab_unpack, dim3(blocks_for(nLo)), dim3(kBlock), 0, e->stream, (const SlabRec*)recvLo, (int)nLo,
-                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, (int)e->nSlots);
+                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, (int)e->nSlots, geom, 1, e->d_slabCnt);
     e->nSlots += nLo;
     if (nHi) hipLaunchKernelGGL(k_slab_unpack, dim3(blocks_for(nHi)), dim3(kBlock), 0, e->stream, (const SlabRec*)recvHi, (int)nHi,
-                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, (int)e->nSlots);
+                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, (int)e->nSlots, geom, 0, e->d_slabCnt);
     e->nSlots += nHi;
     HIP_TRY(hipGetLastError());
     // until the next dispatch sorts again, every slot may hold data
@@ -1215,11 +1226,12 @@ static int slab_unpack_on(SphEngine* e, hipStream_t st, const void* recvLo, cons
     if ((e->hasLo && !lo) || (e->hasHi && !hi)) return fail(SPH_ERR_ARG, "missing receive buffer");
     const int c = e->cur;
     e->nSlots = e->cap;
+    const SlabGeom geom = slab_geom(e);
     Timed t(e, SPH_K_OTHER, st);
     if (lo) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, st, lo, (const SlabRec*)nullptr, recvCap,
-                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap);
+                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap, geom, 1);
     if (hi) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, st, hi, lo, recvCap,
-                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap);
+                               e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap, geom, 0);
     hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, st, e->d_slabCnt, lo, hi, (uint32_t)e->cap, recvCap);
     HIP_TRY(hipGetLastError());
     return SPH_OK;

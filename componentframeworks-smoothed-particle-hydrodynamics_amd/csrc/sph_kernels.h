@@ -810,10 +810,27 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
     slab_append(sendHi, &counters[1], capHi, toHiBuf, r);
 }
 
+// What a received record tells about the exchange's one assumption -- no particle crosses more than one cell layer in z per
+// substep (velocity cap + a container that stays put).  An OWNED record (a migrant) must land inside the receiver's layers, and
+// not in the layer next to its OTHER face: that layer's particles are halo copies on a third rank, and this exchange is already
+// past the point where the receiver could have made one.  Otherwise the run goes on, but no longer equals the single-domain run:
+// counters[4] bit 4.  (fromLo: the record came from the lower neighbour.)
+struct SlabGeom {
+    float gminz, cellSize;
+    int gzGlobal, z0, z1, hasLo, hasHi;
+};
+__device__ __forceinline__ bool slab_record_misplaced(const SlabGeom& g, const SlabRec& r, bool fromLo) {
+    if (r.flags & (F_HALO | F_DEAD)) return false;
+    const int cz = cell_axis(r.pz, g.gminz, g.cellSize, g.gzGlobal);
+    if (cz < g.z0 || cz >= g.z1) return true;                               // belongs to a rank further on
+    if (g.z1 - g.z0 < 2) return false;
+    return fromLo ? (g.hasHi && cz == g.z1 - 1) : (g.hasLo && cz == g.z0);  // a third rank needed its halo copy in this very exchange
+}
+
 // Append received records behind the local slots.
 __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restrict__ recv, int nRecv, float4* __restrict__ pos,
                                                         float4* __restrict__ vel, float2* __restrict__ rp, float* __restrict__ foam,
-                                                        float4* __restrict__ acc, int dstBase) {
+                                                        float4* __restrict__ acc, int dstBase, SlabGeom g, int fromLo, uint32_t* __restrict__ counters) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nRecv) return;
     const SlabRec r = recv[i];
@@ -823,12 +840,14 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
     acc[d] = make_float4(r.ax, r.ay, r.az, 0.0f);
+    if (slab_record_misplaced(g, r, fromLo != 0)) atomicOr(&counters[4], 16u);
 }
 
 // ---- exchange without host round trips: the record count travels in a header record in front of the payload ----
 constexpr uint32_t kSlabMagic = 0x48414c4fu;            // "HALO" in the header's flags word
 // counters: [0] records for the lower neighbour, [1] for the upper one, [2] slots in use, [4] error flags
-// (bit 0: a send buffer overflowed, bit 1: the slab's slot capacity overflowed on unpack).
+// (bit 0: a send buffer overflowed, bit 1: the slab's slot capacity overflowed on unpack, bits 2-3: k_slab_commit,
+// bit 4: a received particle had moved more than one cell layer, slab_record_misplaced).
 __global__ void k_slab_headers(uint32_t* __restrict__ counters, SlabRec* __restrict__ sendLo, SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t nl = counters[0], nh = counters[1];
@@ -848,7 +867,8 @@ __device__ __forceinline__ uint32_t slab_header_count(const SlabRec* __restrict_
 // direction's count when `afterOther` points at that header).
 __global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __restrict__ recv, const SlabRec* __restrict__ afterOther, uint32_t recvCap,
                                                             float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
-                                                            float* __restrict__ foam, float4* __restrict__ acc, uint32_t* __restrict__ counters, uint32_t slotCap) {
+                                                            float* __restrict__ foam, float4* __restrict__ acc, uint32_t* __restrict__ counters, uint32_t slotCap,
+                                                            SlabGeom g, int fromLo) {
     const uint32_t cnt = slab_header_count(recv, recvCap);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= cnt) return;
@@ -861,6 +881,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __res
     rp[d] = make_float2(r.rho, r.prs);
     foam[d] = r.foam;
     acc[d] = make_float4(r.ax, r.ay, r.az, 0.0f);
+    if (slab_record_misplaced(g, r, fromLo != 0)) atomicOr(&counters[4], 16u);
 }
 // counters[4] bit 2: a received header was not a header (magic / count); bit 3: the SENDER had more records than its
 // message could carry (header.pad = its true count), i.e. the neighbour's overflow made visible on this rank too.

@@ -446,9 +446,11 @@ class SlabGroup:
         return out[np.argsort(out["id"], kind="stable")]
 
 
-def merge_into_records(initial: np.ndarray, owned: np.ndarray) -> np.ndarray:
+def merge_into_records(initial: np.ndarray, owned: np.ndarray, stepped: bool = True) -> np.ndarray:
     """Global 80-byte array in ORIGINAL order from the ranks' owned records: dynamic fields come
-    from the owned records (by global id = original index), constant fields from `initial`."""
+    from the owned records (by global id = original index), constant fields from `initial`.
+    Ghosts (isGhost == 1) keep their record, except that an ACTIVE ghost that has been through a substep
+    (`stepped`) carries what SPHFluid.comp:72-83 writes: vel = acc = vec4(0), density = rho0, pressure = 0."""
     out = initial.copy()
     idx = owned["id"].astype(np.int64)
     fluid = (initial["isGhost"][idx] != 1)
@@ -460,4 +462,11 @@ def merge_into_records(initial: np.ndarray, owned: np.ndarray) -> np.ndarray:
     out["density"][i_f] = owned["density"][fluid]
     out["pressure"][i_f] = owned["pressure"][fluid]
     out["padA"][i_f] = owned["padA"][fluid]
+    if stepped:
+        ghost = (~fluid) & (initial["isActive"][idx] != 0)
+        i_g = idx[ghost]
+        out["vel"][i_g, :] = 0.0
+        out["acc"][i_g, :] = 0.0
+        out["density"][i_g] = owned["density"][ghost]      # rho0 of the parameters the substep ran with
+        out["pressure"][i_g] = 0.0
     return out

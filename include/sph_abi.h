@@ -292,7 +292,14 @@ int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap);
 int sph_slab_face_buffer(SphEngine* e, int which /* 0 send lo, 1 send hi, 2 recv lo, 3 recv hi */, void** devPtr);
 int sph_slab_pack_async(SphEngine* e);
 int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap);
-/* Synchronises; out = {records packed for lo, for hi, slots in use, -, error flags}. */
+/* Synchronises; out = {records packed for lo, for hi, slots in use, -, error flags}.  Error flags (device side, sticky; any of
+ * them also makes this call and sph_slab_download return an error): 1 a send face overflowed, 2 the slot capacity overflowed
+ * while appending received records, 4 a received message did not start with a valid header, 8 the neighbour had more records
+ * than its message could carry, 16 a received particle had crossed MORE THAN ONE cell layer in z within one substep (it was
+ * placed far outside the container, or the container moved by cells under the fluid): the exchange hands particles to the
+ * adjacent rank only and halo copies exist one layer deep, so from then on the decomposed run no longer equals the
+ * single-domain run.  (The velocity cap keeps ordinary motion below 0.4 h per substep; the pack after a container change scans
+ * every slot, so a change of shape alone is followed exactly as long as no particle has to cross a whole slab.) */
 int sph_slab_status(SphEngine* e, uint32_t out[5]);
 /* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy: rank 0 creates the id and hands its 128 bytes to the other ranks
  * by any means (MPI, a file, torch.distributed); one rank per process, on the current HIP device. */

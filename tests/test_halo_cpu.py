@@ -20,6 +20,10 @@ def _scene(pkg, oracle):
     rng = np.random.default_rng(3)
     P["vel"][:, 2] += rng.normal(0, 60, len(P)).astype(np.float32)      # plenty of z-migration
     P["vel"][:, 0] += rng.normal(0, 10, len(P)).astype(np.float32)
+    P["isGhost"][300:340] = 1                 # ghosts of every kind: active (the substep zeroes vel / acc), inactive, and "3" (an ordinary particle)
+    P["isActive"][300:320] = 1
+    P["isGhost"][340:360] = 3
+    P["vel"][300:360, 3] = 7.0
     return P, sp, op
 
 
