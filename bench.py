@@ -293,13 +293,16 @@ def main():
             st = sim.engine.status()
             mine = [int(st[0]), int(st[1]), int(st[2]), 0]
         except Exception as ex:                          # noqa: BLE001  (SphError: the status call reports an overflow as an error)
-            mine = [0, 0, 0, 1]
+            mine = [0, 0, 0, 2 if "more than one cell layer" in str(ex) else 1]
             print(f"[rank {rank}] slab status: {ex}", file=sys.stderr, flush=True)
         tst = torch.tensor(mine, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         gathered = [torch.zeros_like(tst) for _ in range(world)]
         dist.all_gather(gathered, tst)
         slab_status = {"records_lo_hi_live_per_rank": [[int(v) for v in g[:3].tolist()] for g in gathered],
-                       "overflow_on_any_rank": bool(sum(int(g[3].item()) for g in gathered)),
+                       "overflow_on_any_rank": any(int(g[3].item()) == 1 for g in gathered),
+                       # a particle crossed more than one cell layer in a substep (error bit 16): the run went on, but it no longer
+                       # equals the single-domain run bit for bit
+                       "multi_layer_move_on_any_rank": any(int(g[3].item()) == 2 for g in gathered),
                        "face_capacity_records": int(sim.engine.face_cap) if hasattr(sim.engine, "face_cap") else None}
 
     if rank != 0:

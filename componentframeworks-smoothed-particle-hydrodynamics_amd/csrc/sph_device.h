@@ -32,6 +32,7 @@ struct SimK {
     float negRest, oneMinusFric;
     int shape;
     int obbDeferred;   // shape 7..14: the SPH pass skips OBB, k_obb_ext applies it afterwards
+    uint32_t* slabFlags;   // z-slab engines, substeps whose following pack may use the reduced scan: the exchange's error flags (slab_check_layer_move); else nullptr
 };
 
 // flag bits packed into pos.w of the internal state
@@ -62,6 +63,24 @@ __device__ __forceinline__ int cell_axis(float p, float gmin, float cellSize, in
 __device__ __forceinline__ int cell_z_global(const SimK& k, float pz) { return cell_axis(pz, k.gminz, k.cellSize, k.gzGlobal); }
 __device__ __forceinline__ int cell_z_local(const SimK& k, float pz) {
     return min(max(cell_z_global(k, pz) - k.zoff, 0), k.gz - 1);
+}
+// z-slab engines.  The exchange is built on ONE assumption: a substep moves a particle across at most one cell layer in z (halo
+// copies are one layer deep, migrants go to the adjacent rank, and while the container stays put the pack looks only at the slots of
+// the three lowest / three highest local layers).  SPHFluid.comp integrates the position with the UNCAPPED velocity (v + a dt) and
+// OBBConstraints.comp projects, so a violent substep can do more.  Where that makes the decomposed run differ from the single-domain
+// run it is REPORTED (error bit 16 of the exchange's flags), not followed:
+//   * here, for the pack's reduced scan: a particle that began the substep OUTSIDE the slot ranges the next pack reads and ends in a
+//     layer that pack would have acted on (a face layer: halo copy; beyond it: migrant);
+//   * in k_slab_unpack*, for migrants that land on a rank that cannot place them (slab_record_misplaced).
+// k.slabFlags is set only for substeps whose following pack may use the reduced scan.
+__device__ __forceinline__ void slab_check_layer_move(const SimK& k, int czEntryLocal, float pzNew) {
+    if (!k.slabFlags) return;                                      // (kernel-uniform)
+    if (czEntryLocal < 3 || czEntryLocal > k.gz - 4) return;       // the pack reads this slot anyway
+    // half a cell of margin around the exact test, so that nearly every particle leaves after two comparisons
+    const float zLo = fmaf((float)(k.zoff + 2) + 0.5f, k.cellSize, k.gminz), zHi = fmaf((float)(k.zoff + k.gz - 2) - 0.5f, k.cellSize, k.gminz);
+    if (pzNew > zLo && pzNew < zHi) return;
+    const int czNew = cell_z_global(k, pzNew) - k.zoff;
+    if (czNew <= 1 || czNew >= k.gz - 2) atomicOr(k.slabFlags, 16u);
 }
 
 // ======================= SPHFluid.comp main(), per-particle / per-pair arithmetic =======================

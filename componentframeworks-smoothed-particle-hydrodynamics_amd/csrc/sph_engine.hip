@@ -388,6 +388,11 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
     if (e->slab) {
         if (e->z1 > e->grid.dims[2] || e->z0 < 0) return fail(SPH_ERR_STATE, "slab [%d,%d) outside the %d-layer grid", e->z0, e->z1, e->grid.dims[2]);
         k.gz = e->z1 - e->z0 + 2; k.numCells = k.gx * k.gy * k.gz; k.zoff = e->z0 - 1;
+        // the pack that follows this substep may restrict itself to the ends of the slot range (same container as the substep
+        // before, sorted slots): a particle that this substep carries from the middle into a face layer is then reported
+        float contNow[15];
+        container_key(e->params, contNow);
+        if (e->optGridBuild != 1 && std::memcmp(contNow, e->lastContainer, sizeof(contNow)) == 0) k.slabFlags = e->d_slabCnt + 4;
     }
     if ((rc = import_state(e))) return rc;
     const int n = (int)(e->slab ? e->nSlots : e->n);
@@ -460,7 +465,8 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
     if (n && k.obbDeferred) {                                               // :495-509 for shapes 7..14
         Timed t(e, SPH_K_OTHER);
         const uint32_t* live = (e->slab && e->optGridBuild != 1) ? e->d_cellStart + k.numCells : nullptr;
-        hipLaunchKernelGGL(k_obb_ext, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->shapeTab, out.pos, out.vel, live, n);
+        hipLaunchKernelGGL(k_obb_ext, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, e->shapeTab, out.pos, out.vel, live, n,
+                           (e->slab && e->optGridBuild != 1) ? (const float4*)e->d_sOwn : (const float4*)nullptr);
     }
     const bool riverOn = e->river.riverMode && !e->terrainHeights.empty();   // :512
     if (riverOn) {                                                           // :511-516, DispatchTerrainConstraints / ChannelConstraint / StreamEmit
@@ -505,7 +511,8 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
         const bool sorted = e->optGridBuild != 1 && n > 0;
         if (!sorted) HIP_TRY(hipMemcpyAsync(e->d_slabCnt + 2, e->d_cellStart + k.numCells, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));   // (k_rank stored it otherwise)
         // the next k_slab_pack may restrict itself to the ends of the slot range if this substep cannot have moved a
-        // particle by more than one layer: velocity cap (always), and a container that did not change under the fluid
+        // particle by more than one layer: a container that did not change under the fluid (and the SPH pass reports the particle that
+        // jumps from the middle into a face layer all the same, slab_check_layer_move)
         float cont[15];
         container_key(e->params, cont);
         const bool sameContainer = std::memcmp(cont, e->lastContainer, sizeof(cont)) == 0;

@@ -126,6 +126,7 @@ inline void make_simk(const SphParams& p, const SphGridInfo& g, float dt, SimK& 
     k.oneMinusFric = 1.0f - p.param_wallFriction;
     k.shape = p.param_shapeType;
     k.obbDeferred = (k.shape >= 7 && k.shape <= 14) ? 1 : 0;
+    k.slabFlags = nullptr;
 }
 
 // ---- spawn -------------------------------------------------------------------------

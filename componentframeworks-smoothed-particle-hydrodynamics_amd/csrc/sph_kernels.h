@@ -266,7 +266,7 @@ __device__ __forceinline__ void aos_write_active_ghost(SphParticle* __restrict__
 // OBBConstraints.comp for container shapes 7..14, applied to the SPH pass's output state
 // (slot order).  liveCount (nullable) bounds the slots that hold particles in slab mode.
 __global__ __launch_bounds__(kBlock) void k_obb_ext(SimK k, ShapeTab T, float4* __restrict__ pos, float4* __restrict__ vel,
-                                                    const uint32_t* __restrict__ liveCount, int n) {
+                                                    const uint32_t* __restrict__ liveCount, int n, const float4* __restrict__ own) {
     const int s = blockIdx.x * kBlock + threadIdx.x;
     const int bound = liveCount ? min(n, (int)*liveCount) : n;
     if (s >= bound) return;
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_obb_ext(SimK k, ShapeTab T, float4* 
     float4 V = vel[s];
     obb_apply_ext(k, T, P.x, P.y, P.z, V.x, V.y, V.z);
     pos[s] = P; vel[s] = V;
+    if (k.slabFlags && own) slab_check_layer_move(k, (int)(fbits(own[s].x) >> 20), P.z);   // against the layer the substep began in (sorted copy, still in slot order)
 }
 
 // shaders/FountainRecycle.comp:24-54 on the SPH pass's output state.  The particle index of the
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
     const int n = min(nBound, (int)counters[2]);       // counters[2] = slots that hold data (live count of the last sort)
     if ((int)(blockIdx.x * kBlock) >= n) return;       // whole block beyond the data
     // cellStart != nullptr: the slots are still in the order of the last counting sort (z-major) and nothing moved a
-    // particle by more than one cell layer since (velocity cap, unchanged container).  Everything this pass acts on --
+    // particle by more than one cell layer since (unchanged container; a substep that did is reported, slab_check_layer_move).  Everything this pass acts on --
     // stale ghosts, face particles, migrants -- then entered that substep in one of the three lowest or three highest
     // local layers, i.e. sits in two slot ranges at the ends; blocks in between have nothing to do.
     bool inEnds = true;
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
 }
 
 // What a received record tells about the exchange's one assumption -- no particle crosses more than one cell layer in z per
-// substep (velocity cap + a container that stays put).  An OWNED record (a migrant) must land inside the receiver's layers, and
+// substep.  An OWNED record (a migrant) must land inside the receiver's layers, and
 // not in the layer next to its OTHER face: that layer's particles are halo copies on a third rank, and this exchange is already
 // past the point where the receiver could have made one.  Otherwise the run goes on, but no longer equals the single-domain run:
 // counters[4] bit 4.  (fromLo: the record came from the lower neighbour.)

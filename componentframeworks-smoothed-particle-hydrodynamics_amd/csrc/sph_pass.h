@@ -24,8 +24,9 @@ struct SortedIn {
 
 __device__ __forceinline__ void store_fields(const SimK& k, const StateOut& out, int s, uint32_t flags, uint32_t id, float px, float py,
                                              float pz, float vx, float vy, float vz, float ax, float ay, float az, float rho, float prs,
-                                             float foamOut) {
+                                             float foamOut, int czEntry) {
     if (!(flags & F_GHOSTNZ)) obb_apply(k, px, py, pz, vx, vy, vz);   // OBBConstraints.comp:46
+    slab_check_layer_move(k, czEntry, pz);
     out.pos[s] = make_float4(px, py, pz, bitsf(flags));
     out.vel[s] = make_float4(vx, vy, vz, bitsf(id));
     out.rp[s] = make_float2(rho, prs);
@@ -85,7 +86,7 @@ __device__ __forceinline__ void sph_slow_one(const SimK& k, const SortedIn& S, c
         pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, (int32_t)((int)q != s ? -1 : 0));
     });
     const float foamOut = finish_particle(k, o, O.y);
-    store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+    store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, cz);
 }
 
 __global__ __launch_bounds__(kBlock) void k_sph_slow(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
@@ -328,14 +329,14 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
     auto force_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
     auto xsph_at = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
 #if defined(SPH_LIST_CUT) && SPH_LIST_CUT == 1   // timing experiment only (tools/ab_variants.sh): stop after sweep 1
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cnt, o.ay, o.az, o.rho, o.prs, O.y);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cnt, o.ay, o.az, o.rho, o.prs, O.y, cz);
     return;
 #endif
     // ---- sweep 2 ----
     if (listOk) listed(cnt, force_at); else chunked(o.px, o.py, o.pz, force_at);
     integrate(k, o);
 #if defined(SPH_LIST_CUT) && SPH_LIST_CUT == 2   // timing experiment only: stop after sweep 2
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, O.y);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, O.y, cz);
     return;
 #endif
     // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(SPH_LIST_BLOCK, SPH_LIST_WAVES) void k_sph_list(Sim
     const bool near = (dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2)) || !live;
     if (listOk && near) listed(cnt, xsph_at); else chunked(o.px, o.py, o.pz, xsph_at);
     const float foamOut = finish_particle(k, o, O.y);
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, cz);
     if (dbg & 8) {   // diagnostics: [1] targets on an exact fallback sweep, [2] list entries, [4] lanes
         const unsigned long long slowT = (unsigned long long)__popcll(__ballot(live && !(listOk && near)));
         unsigned long long ents = (unsigned long long)(live ? cnt : 0);

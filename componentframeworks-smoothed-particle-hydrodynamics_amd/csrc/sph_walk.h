@@ -302,14 +302,14 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     auto force_plain = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
     auto xsph_plain = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
 #if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 1   // timing experiment only: stop after sweep 1
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cur, o.ay, o.az, o.rho, o.prs, O.y);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cur, o.ay, o.az, o.rho, o.prs, O.y, cz);
     return;
 #endif
     // ---- sweep 2 ----
     if (listOk) listed(force_at); else plain(force_plain);
     integrate(k, o);
 #if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 2   // timing experiment only: stop after sweep 2
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, O.y);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, O.y, cz);
     return;
 #endif
     // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     const bool near = (dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2)) || !live;
     if (listOk && near) listed(xsph_at); else plain(xsph_plain);
     const float foamOut = finish_particle(k, o, O.y);
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, cz);
     if (dbg & 8) {   // diagnostics: [0] candidate rows walked from global memory (window too large), [3] candidate rows, [1] targets on an exact fallback sweep, [2] list entries, [4] lanes, [5] overflowed lists, [6] far targets, [7] waves with a fallback
         const unsigned long long slowT = (unsigned long long)__popcll(__ballot(live && !(listOk && near)));
         unsigned long long ents = (unsigned long long)((live && listOk) ? (cur - (uint32_t)tid * 2u) / kRowBytes : 0u);

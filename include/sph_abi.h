@@ -298,7 +298,8 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
  * than its message could carry, 16 a received particle had crossed MORE THAN ONE cell layer in z within one substep (it was
  * placed far outside the container, or the container moved by cells under the fluid): the exchange hands particles to the
  * adjacent rank only and halo copies exist one layer deep, so from then on the decomposed run no longer equals the
- * single-domain run.  (The velocity cap keeps ordinary motion below 0.4 h per substep; the pack after a container change scans
+ * single-domain run.  (SPHFluid.comp moves a particle with the uncapped velocity (v + a dt) dt, so this is a property of the scene, not a guarantee:
+ * the BASELINE workloads keep it through their whole collapse; the pack after a container change scans
  * every slot, so a change of shape alone is followed exactly as long as no particle has to cross a whole slab.) */
 int sph_slab_status(SphEngine* e, uint32_t out[5]);
 /* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy: rank 0 creates the id and hands its 128 bytes to the other ranks
@@ -313,8 +314,8 @@ int sph_comm_selftest(SphComm* comm, uint64_t bytes);
 int sph_slab_exchange(SphEngine* e, SphComm* comm);
 /* ---- boundary-first substep: the exchange hidden behind the interior of the SPH pass -----------------------------
  * sph_slab_step_begin = sph_dispatch, except that the SPH pass runs the slot ranges next to the slab's faces first (the
- * three lowest / three highest local cell layers: everything the next pack can touch, since the velocity cap bounds a
- * substep's move to one layer), and then, on a second stream of the engine, the pack of the exchange that prepares the
+ * three lowest / three highest local cell layers: everything the next pack can touch as long as a substep moves a particle
+ * across at most one layer; a substep that does not is reported, error flag 16 above), and then, on a second stream of the engine, the pack of the exchange that prepares the
  * NEXT substep -- while the interior slots are still being computed on the engine's stream.  The second half moves the
  * faces and unpacks, still on the second stream; the engine's stream waits for it only at its end:
  *   sph_slab_step_finish(engine, comm)            one process per GPU: grouped ncclSend / ncclRecv (RCCL over xGMI)

@@ -82,10 +82,22 @@ def test_the_fuzz_reaches_both_template_instances_and_the_fallbacks(pkg):
     assert hs == {True, False} and dense >= 3 and fast >= 3
 
 
-# Seeds whose scene breaks the decomposition's one assumption (no particle crosses more than one cell layer in z per substep):
-# particles placed far outside a ROTATED container are projected back across several layers by the first substep's OBB pass.
-# The exchange must say so (error bit 4 of sph_slab_status, raised by the receiving rank); everything else must be bit-exact.
-MULTI_LAYER_SEEDS = {0}
+# The decomposition's one assumption: no particle crosses more than one cell layer in z per substep.  SPHFluid.comp moves a particle
+# with the UNCAPPED velocity (v + a dt) dt and OBBConstraints.comp projects it, so violent scenes (20 particles per cell, particles
+# placed outside a rotated container) break it.  Where such a jump makes the slabs differ from the single domain the engine must SAY
+# so (error bit 16 of sph_slab_status: raised by the SPH pass of the owning rank when the pack's reduced scan would miss the
+# particle, or by the rank that receives a migrant it cannot place); a run that stays silent must be bit-exact, and a report is
+# only legitimate where the oracle sees a jump of more than one layer.
+def _layer_jumps(oracle, op, rec, g, dims, steps):
+    gm, cs = np.float32(g.gridMin[2]), np.float32(g.cellSize)
+    layer = lambda P: np.clip(np.floor(((P["pos"][:, 2] - gm) / cs).astype(np.float32)), 0, dims[2] - 1).astype(np.int64)
+    cur, worst = rec, 0
+    for _ in range(steps):
+        nxt = oracle.substep(cur, op)
+        moving = rec["isGhost"] != 1
+        worst = max(worst, int(np.abs(layer(nxt) - layer(cur))[moving].max(initial=0)))
+        cur = nxt
+    return worst, cur
 
 
 @pytest.mark.parametrize("seed", list(range(28)))
@@ -105,7 +117,7 @@ def test_random_scene_as_z_slabs_with_boundary_first_steps(pkg, oracle, seed):
         pytest.skip(f"grid {dims} too thin for {world} slabs")
     steps += 2
     op = to_oracle_params(oracle, sp)
-    want = oracle.substep(rec, op, steps=steps)
+    worst_jump, want = _layer_jumps(oracle, op, rec, g, dims, steps)
     q = ((rec["pos"][:, 2] - np.float32(g.gridMin[2])) / np.float32(g.cellSize)).astype(np.float32)
     cz = np.clip(np.floor(q), 0, dims[2] - 1).astype(np.int64)
     ids = np.arange(len(rec), dtype=np.uint32)
@@ -126,11 +138,11 @@ def test_random_scene_as_z_slabs_with_boundary_first_steps(pkg, oracle, seed):
         except pkg.SphError as ex:
             assert "more than one cell layer" in str(ex), ex
             reported.append(str(ex))
-    if seed in MULTI_LAYER_SEEDS:
-        assert reported, f"seed {seed}: the multi-layer jump went unreported: {what}"
+    if reported:                                   # allowed only where a particle did cross more than one layer in some substep
+        assert worst_jump > 1, f"seed {seed}: largest layer jump {worst_jump}, yet: {reported[0]}: {what}"
         for s in grp.sims:
             s.engine.close()
         return
-    assert not reported, f"seed {seed}: {reported[0]}: {what}"
+    # silence means: the decomposition followed every particle
     got = halo.merge_into_records(rec, grp.download())
     assert_records_equal(got, want, f"seed {seed} as {world} slabs: {what}")
