@@ -146,3 +146,95 @@ def test_random_scene_as_z_slabs_with_boundary_first_steps(pkg, oracle, seed):
     # silence means: the decomposition followed every particle
     got = halo.merge_into_records(rec, grp.download())
     assert_records_equal(got, want, f"seed {seed} as {world} slabs: {what}")
+
+
+# ---- random call sequences on one engine -------------------------------------------------------------------------------------
+def _mirror(pkg, oracle, seed):
+    """A random scene, then 14-22 random calls of the SPHFluidGPU surface, each mirrored on the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    rec, sp, _, what = _scene(pkg, seed + 100)
+    if len(rec) > 6000:                                   # keep the oracle quick: the interest here is the engine's state handling
+        rec = rec[:6000].copy()
+    f = pkg.SPHFluidGPU.from_particles(rec, sp)
+    op = to_oracle_params(oracle, f.params)
+    want = rec.copy()
+    log = []
+    h = float(sp.param_h)
+    targets = rng.uniform(-2 * h, 2 * h, (64, 4)).astype(np.float32)
+    f.SetStencilTargets(targets)
+    for _ in range(int(rng.integers(14, 23))):
+        opn = rng.choice(["dispatch", "dispatch", "dispatch", "dispatch_n", "wave", "vortex", "attractor", "curl", "stencil", "param", "option",
+                          "download", "upload", "device", "container"])
+        if opn == "dispatch":
+            dt = float(rng.choice([-1.0, -1.0, 5e-4, 1.5e-3]))
+            f.DispatchCompute(dt); want = oracle.substep(want, op, dt=dt)
+        elif opn == "dispatch_n":
+            k = int(rng.integers(2, 5))
+            f.DispatchN(k); want = oracle.substep(want, op, steps=k)
+        elif opn == "wave":
+            a = (float(rng.uniform(0.2, 2.0)), float(rng.uniform(1.0, 4.0)), float(rng.uniform(0, 6.0)), (0.3, 1.0, -0.2), -2.0 * h * 5, 3.0 * h * 5)
+            f.ApplyWaveImpulse(*a); want = oracle.wave_impulse(want, *a)
+        elif opn == "vortex":
+            a = (float(rng.uniform(-1, 1)), float(rng.uniform(-0.3, 0.3)))
+            f.ApplyVortexImpulse(*a); want = oracle.vortex_impulse(want, op, *a)
+        elif opn == "attractor":
+            a = ((float(rng.uniform(-h, h)), float(rng.uniform(-h, h)), 0.1), float(rng.uniform(0.1, 0.8)), float(rng.uniform(2 * h, 8 * h)))
+            f.ApplyAttractorImpulse(*a); want = oracle.attractor_impulse(want, *a)
+        elif opn == "curl":
+            a = (float(rng.uniform(0.1, 0.6)), float(rng.uniform(0.3, 1.5)), float(rng.uniform(0, 3)))
+            f.ApplyCurlFlow(*a); want = oracle.curl_flow(want, *a)
+        elif opn == "stencil":
+            a = (float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.0, 0.05)))
+            f.ApplyStencilAttract(*a); want = oracle.stencil_attract(want, targets, *a)
+        elif opn == "param":
+            which = rng.choice(["viscosity", "gasConstant", "gravityY", "timeStep", "surfaceTension", "wallRestitution", "pause"])
+            if which == "viscosity": f.param_viscosity = float(rng.uniform(1, 8))
+            elif which == "gasConstant": f.param_gasConstant = float(rng.uniform(500, 4000))
+            elif which == "gravityY": f.param_gravityY = float(rng.uniform(-1500, 200))
+            elif which == "timeStep": f.param_timeStep = float(rng.choice([5e-4, 1e-3, 2e-3]))
+            elif which == "surfaceTension": f.param_surfaceTension = float(rng.uniform(0, 0.2))
+            elif which == "wallRestitution": f.param_wallRestitution = float(rng.uniform(0, 0.9))
+            else: f.param_pause = int(1 - f.param_pause)
+            op = to_oracle_params(oracle, f.params)
+            opn = f"param {which}"
+        elif opn == "container":                             # the walls (and with them the grid) change under the fluid
+            which = rng.choice(["half", "euler", "shape"])
+            if which == "half":
+                f.param_boxHalf = tuple(float(x) * float(rng.uniform(0.8, 1.15)) for x in f.param_boxHalf)
+            elif which == "euler":
+                f.param_boxEulerDeg = tuple(float(rng.uniform(-30, 30)) for _ in range(3))
+            else:
+                f.param_shapeType = int(rng.integers(0, 15))
+            op = to_oracle_params(oracle, f.params)
+            opn = f"container {which}"
+        elif opn == "option":
+            which = rng.choice(["neighbor", "aos", "graph"])
+            if which == "neighbor": f.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, int(rng.choice([1, 2, 3, 3])))
+            elif which == "aos": f.set_option(pkg.SPH_OPT_AOS_MODE, int(rng.integers(0, 2)))
+            else: f.set_option(pkg.SPH_OPT_GRAPH, int(rng.integers(0, 2)))
+            opn = f"option {which}"
+        elif opn == "download":
+            assert_records_equal(f.download(), want, f"seed {seed} after {log}")
+        elif opn == "upload":                                # the host edits records (as Scene0p does for its dye patterns) and uploads them
+            cur = f.download()
+            assert_records_equal(cur, want, f"seed {seed} before upload after {log}")
+            pick = rng.choice(len(cur), size=max(1, len(cur) // 10), replace=False)
+            cur["vel"][pick, :3] += rng.normal(0, 5, (len(pick), 3)).astype(np.float32)
+            cur["isGhost"][pick[: len(pick) // 4]] = 1
+            cur["isActive"][pick[: len(pick) // 8]] = 0
+            f.upload(cur); want = cur.copy()
+        elif opn == "device":
+            assert f.device_particles() != 0
+        log.append(opn)
+    return f, want, log, what
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_call_sequences_against_the_oracle(pkg, oracle, seed):
+    """Every public call in random order -- substeps, the five impulses, live parameter and container edits, option switches
+    (pass, record mode, graph replay), uploads of edited records, downloads -- leaves the engine where the oracle is."""
+    f, want, log, what = _mirror(pkg, oracle, seed)
+    try:
+        assert_records_equal(f.download(), want, f"seed {seed}: {what}: {log}")
+    finally:
+        f.close()
