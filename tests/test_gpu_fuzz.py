@@ -238,3 +238,79 @@ def test_random_call_sequences_against_the_oracle(pkg, oracle, seed):
         assert_records_equal(f.download(), want, f"seed {seed}: {what}: {log}")
     finally:
         f.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
+    """What a multi-GPU caller does between the substeps of a slab group -- wave impulses, live parameter edits, a container that
+    changes shape under the fluid, time-step overrides -- in random order, with boundary-first steps: the merged records equal the
+    oracle's unless the exchange reports a particle it could not follow (and then the oracle must show such a jump)."""
+    import importlib
+    import torch
+    from conftest import PKG_NAME
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    rng = np.random.default_rng(9000 + seed)
+    rec, sp, _, what = _scene(pkg, seed + 300)
+    if len(rec) > 6000:
+        rec = rec[:6000].copy()
+    g = pkg.compute_grid_extents(sp)
+    dims = tuple(int(v) for v in g.dims)
+    world = 3 if dims[2] >= 9 else 2
+    if dims[2] < 2 * world:
+        pytest.skip(f"grid {dims} too thin for {world} slabs")
+    op = to_oracle_params(oracle, sp)
+    gm, cs = np.float32(g.gridMin[2]), np.float32(g.cellSize)
+    layer = lambda P: np.clip(np.floor(((P["pos"][:, 2] - gm) / cs).astype(np.float32)), 0, dims[2] - 1).astype(np.int64)
+    cz = layer(rec)
+    ids = np.arange(len(rec), dtype=np.uint32)
+
+    def make_engine(p, i, prm, z0, z1, lo, hi):
+        return halo.HipSlabEngine(p, i, prm, z0, z1, lo, hi, capacity=int(len(rec) * 1.2) + 8192)
+
+    face = len(rec) + 1024
+    grp = halo.SlabGroup.from_particles(rec, ids, sp, dims, world, make_engine,
+                                        lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), face, cz)
+    grp.enable_overlap(face)
+    want, worst, log = rec.copy(), 0, []
+    moving = rec["isGhost"] != 1
+    for _ in range(int(rng.integers(10, 18))):
+        opn = rng.choice(["dispatch", "dispatch", "dispatch", "wave", "param", "shape"])
+        if opn == "dispatch":
+            dt = float(rng.choice([-1.0, -1.0, 5e-4]))
+            grp.DispatchCompute(dt)
+            nxt = oracle.substep(want, op, dt=dt)
+            worst = max(worst, int(np.abs(layer(nxt) - layer(want))[moving].max(initial=0)))
+            want = nxt
+        elif opn == "wave":
+            a = (float(rng.uniform(0.2, 2.0)), float(rng.uniform(1.0, 4.0)), float(rng.uniform(0, 6.0)), (0.3, 1.0, -0.2), -1e9, 1e9)
+            grp.ApplyWaveImpulse(*a); want = oracle.wave_impulse(want, *a)
+        elif opn == "param":
+            which = rng.choice(["viscosity", "gasConstant", "gravityY", "timeStep"])
+            if which == "viscosity": sp.param_viscosity = float(rng.uniform(1, 8))
+            elif which == "gasConstant": sp.param_gasConstant = float(rng.uniform(500, 4000))
+            elif which == "gravityY": sp.param_gravityY = float(rng.uniform(-1500, 200))
+            else: sp.param_timeStep = float(rng.choice([5e-4, 1e-3]))
+            op = to_oracle_params(oracle, sp)
+            opn = f"param {which}"
+        else:                                                # box <-> sphere of the same extent: the grid stays, the walls move by cells
+            old = int(sp.param_shapeType)
+            sp.param_shapeType = 1 if old == 0 else 0
+            if tuple(int(v) for v in pkg.compute_grid_extents(sp).dims) != dims:
+                sp.param_shapeType = old
+                continue
+            op = to_oracle_params(oracle, sp)
+        log.append(opn)
+    reported = []
+    for s in grp.sims:
+        try:
+            assert s.engine.status()[4] == 0
+        except pkg.SphError as ex:
+            assert "more than one cell layer" in str(ex), ex
+            reported.append(str(ex))
+    if reported:
+        assert worst > 1, f"seed {seed}: largest layer jump {worst}, yet: {reported[0]}: {what}: {log}"
+    else:
+        got = halo.merge_into_records(rec, grp.download())
+        assert_records_equal(got, want, f"seed {seed} as {world} slabs: {what}: {log}")
+    for s in grp.sims:
+        s.engine.close()
