@@ -162,15 +162,27 @@ def _mirror(pkg, oracle, seed):
     h = float(sp.param_h)
     targets = rng.uniform(-2 * h, 2 * h, (64, 4)).astype(np.float32)
     f.SetStencilTargets(targets)
+    of = oracle.default_fountain(mode=0, seed=int(f.fountainSeed))        # FountainRecycle.comp, step 6 of DispatchCompute, while fountainMode is on
+    fountain = lambda: of if of.mode else None
     for _ in range(int(rng.integers(14, 23))):
         opn = rng.choice(["dispatch", "dispatch", "dispatch", "dispatch_n", "wave", "vortex", "attractor", "curl", "stencil", "param", "option",
-                          "download", "upload", "device", "container"])
+                          "download", "upload", "device", "container", "fountain"])
         if opn == "dispatch":
             dt = float(rng.choice([-1.0, -1.0, 5e-4, 1.5e-3]))
-            f.DispatchCompute(dt); want = oracle.substep(want, op, dt=dt)
+            f.DispatchCompute(dt); want = oracle.substep(want, op, dt=dt, fountain=fountain())
         elif opn == "dispatch_n":
             k = int(rng.integers(2, 5))
-            f.DispatchN(k); want = oracle.substep(want, op, steps=k)
+            f.DispatchN(k); want = oracle.substep(want, op, steps=k, fountain=fountain())
+        elif opn == "fountain":
+            if of.mode and rng.random() < 0.4:
+                f.fountainMode = 0; of.mode = 0
+            else:
+                off = (float(rng.uniform(-h, h)), float(rng.uniform(-6 * h, 0.0)), float(rng.uniform(-h, h)))
+                rate, level = float(rng.uniform(50, 600)), float(rng.uniform(0.5 * h, 6 * h))
+                f.fountainMode = 1; f.fountainOffset = off; f.fountainDrainPerSec = rate; f.fountainDrainLevel = level
+                of.mode = 1; of.drainPerSec = rate; of.drainLevel = level
+                for a_ in range(3):
+                    of.offset[a_] = off[a_]
         elif opn == "wave":
             a = (float(rng.uniform(0.2, 2.0)), float(rng.uniform(1.0, 4.0)), float(rng.uniform(0, 6.0)), (0.3, 1.0, -0.2), -2.0 * h * 5, 3.0 * h * 5)
             f.ApplyWaveImpulse(*a); want = oracle.wave_impulse(want, *a)
@@ -226,6 +238,7 @@ def _mirror(pkg, oracle, seed):
         elif opn == "device":
             assert f.device_particles() != 0
         log.append(opn)
+    assert int(f.fountainSeed) == int(of.seed), (int(f.fountainSeed), int(of.seed), log)
     return f, want, log, what
 
 
