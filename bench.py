@@ -30,6 +30,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--slab-path", action="store_true", help="rehearsal: run the N > 1 code path (z-slab engine, RCCL communicator, boundary-first substeps, status gather) with however many ranks there are, also one")
     # defaults keep the timed window on the SPECIFIED workload (the seeded lattice state): the 35-unit
     # column of configs[2] is not hydrostatically stable at k = 2000, g = -980 and collapses within a
     # few hundred substeps, which turns the run into a different, denser workload
@@ -109,6 +110,7 @@ def main():
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             raise SystemExit(subprocess.run(cmd, env=env).returncode)
         args.gpus = world
+    multi = args.gpus > 1 or args.slab_path              # the z-slab code path (--slab-path: also with a single rank, as a rehearsal)
 
     import numpy as np
     import torch
@@ -123,9 +125,15 @@ def main():
     pkg = importlib.import_module(PKG)
     syn = pkg.synthetic
 
-    if args.gpus > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:                   # --slab-path without a launcher: a group of one
+            import socket
+            with socket.socket() as sck:
+                sck.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sck.getsockname()[1]))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -137,7 +145,7 @@ def main():
 
     wl = args.workload
     if wl == "auto":
-        wl = "config3" if args.gpus == 1 else "weak5"
+        wl = "config3" if not multi else "weak5"
     if wl == "config2":
         base = syn.CONFIGS[2]
     elif wl == "config3":
@@ -151,7 +159,7 @@ def main():
     sp = pkg.default_params(**syn.params_fields(cfg))
     stream = torch.cuda.current_stream().cuda_stream
 
-    if args.gpus == 1:
+    if not multi:
         rec, _ = syn.make_particles(cfg)
         sim = pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream)
         n_local, n_total = len(rec), len(rec)
@@ -179,7 +187,7 @@ def main():
     # lazy records, one GPU: the renderer's view (the 80-byte array in original order) is brought up to date once per
     # frame, as Scene0p binds it once per frame after up to 16 substeps (Scene0p.cpp:1482-1494, :1625); that work is part
     # of the timed region.  z-slab runs never held a fused record array (owned records are gathered by download_owned()).
-    frame = args.frame_substeps if (args.gpus == 1 and args.aos == "lazy") else 0
+    frame = args.frame_substeps if (not multi and args.aos == "lazy") else 0
     materialised = {"n": 0}
 
     def present():
@@ -204,7 +212,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if args.gpus == 1 and args.aos == "lazy":
+    if not multi and args.aos == "lazy":
         present()                                  # the timed region ends with a current record array
     barrier()
     elapsed = time.perf_counter() - t0
@@ -226,7 +234,7 @@ def main():
         bt = sim.kernel_times(reset=True)
         sim.set_option(pkg.SPH_OPT_TIMING, 0)
         breakdown = {k: round(ms / nb * 1e3, 2) for k, (ms, cnt) in bt.items() if cnt}
-        if args.gpus == 1 and args.grid_build == "sort":
+        if not multi and args.grid_build == "sort":
             # untimed, for the record: the two other (bit-identical) SPH passes at the state the run has reached
             alt = {}
             for name, kind in (("k_sph_walk", 3), ("k_sph_list", 2), ("k_sph_slow", 1)):
@@ -245,7 +253,7 @@ def main():
     # the headline window above is the specified lattice state; this block records, untimed for `value`, what the
     # SAME run costs once the fluid has settled into the compressed regime every long-running scene lives in.
     settled = None
-    if args.gpus == 1 and args.settled_after > 0 and not args.no_breakdown:
+    if not multi and args.settled_after > 0 and not args.no_breakdown:
         done = wave["n"]
         while wave["n"] < args.settled_after:
             step()
@@ -266,7 +274,7 @@ def main():
     # For the record (untimed for `value`): the same workload and window on a fresh engine with the records updated
     # by every substep (SPH_OPT_AOS_MODE 0), i.e. what the fused scattered record update costs.
     aos_eager = None
-    if args.gpus == 1 and args.aos == "lazy" and not args.no_breakdown and args.grid_build == "sort":
+    if not multi and args.aos == "lazy" and not args.no_breakdown and args.grid_build == "sort":
         sim2 = pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream)
         sim2.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
         sim2.set_option(pkg.SPH_OPT_AOS_MODE, 0)
@@ -288,7 +296,7 @@ def main():
     # z-slab runs: overflow of a face buffer or of the slot capacity is flagged on the device, never fatal in the
     # substep loop; a run that dropped records is not a measurement, so every rank's flags go into the line.
     slab_status = None
-    if args.gpus > 1:
+    if multi:
         try:
             st = sim.engine.status()
             mine = [int(st[0]), int(st[1]), int(st[2]), 0]
@@ -311,8 +319,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    g = sim.ComputeGridExtents() if args.gpus == 1 else sim.local_grid()
-    C_local = int(g.numCells) if args.gpus == 1 else int(g["numCells"])
+    g = sim.ComputeGridExtents() if not multi else sim.local_grid()
+    C_local = int(g.numCells) if not multi else int(g["numCells"])
     sph_ms, sph_launches = kt["sph"]
     sph_avg_s = (sph_ms / max(sph_launches, 1)) * 1e-3
     alg_bytes = 164 * n_local + 4 * C_local          # SPHFluid pass, per launch
@@ -325,7 +333,7 @@ def main():
     valu = None
     cpath = os.path.join(ROOT, "profiles", "r03_bench_counters.json")
     kname = "k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor]
-    if os.path.exists(cpath) and args.gpus == 1:
+    if os.path.exists(cpath) and not multi:
         try:
             cj = json.load(open(cpath))
             here = pkg.build.csrc_hash()
@@ -351,15 +359,16 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{wl}: {base.n} particles and a {gx}x{gy}x{gz}-cell grid per GPU (BASELINE.json configs[{base.index - 1}]"
-                        + (f", weak-scaled along z to {args.gpus} slabs" if args.gpus > 1 else "") + ")"
+                        + (f", weak-scaled along z to {args.gpus} slabs" if multi else "") + ")"
                         + ("" if backend == "nccl" else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]"),
+                        # (--slab-path with one rank: the same code path, a communicator of one, no neighbour to exchange with)
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
             "neighbor_kernel": (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor],
-            "aos": (args.aos if args.gpus > 1 or args.aos == "eager" else
+            "aos": (args.aos if multi or args.aos == "eager" else
                     f"lazy: 80-byte records materialised (sph_device_particles) every {frame} substeps and at the end, inside the timed region: {records_materialised} times in {args.steps} substeps"),
             "pipeline": (("bin+scan+scatter+rank -> sph(27-cell, OBB fused" if args.grid_build == "sort" else "ll clear+build -> sph(list walk, OBB fused")
-                         + (", AoS update fused)" if (args.aos == "eager" and args.gpus == 1) else ") -> record write-back once per frame" if args.gpus == 1 else ")"))
-                        + (" + halo exchange" if args.gpus > 1 else ""),
+                         + (", AoS update fused)" if (args.aos == "eager" and not multi) else ") -> record write-back once per frame" if not multi else ")"))
+                        + (" + halo exchange" if multi else ""),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -377,7 +386,7 @@ def main():
         "settled": settled,
         "valu": valu,
     }
-    if not args.no_cpu_baseline and args.gpus == 1:
+    if not args.no_cpu_baseline and not multi:
         out["cpu_baseline"] = cpu_baseline(pkg, rec, sp, args.cpu_steps)
     elif not args.no_cpu_baseline:
         out["cpu_baseline"] = None

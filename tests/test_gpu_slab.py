@@ -363,3 +363,24 @@ def test_rccl_send_recv_to_self_in_a_child_process(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, str(script), ROOT, PKG_NAME], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert res.returncode == 0 and "SELFTEST OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_bench_slab_path_with_rccl_and_one_rank():
+    """`python bench.py --slab-path`: the code path the driver's N > 1 runs take -- torch.distributed with backend nccl (= RCCL),
+    halo.SlabSimulation.from_config(transport="rccl") with the engine's own communicator, boundary-first substeps
+    (sph_slab_step_begin / sph_slab_step_finish), WaveImpulse every 16th substep, the status all_gather -- with the ONE rank this
+    box can give it (RCCL refuses two ranks on a device).  In a child process with a timeout."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SPH_BENCH_BACKEND")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--slab-path", "--workload", "weak5", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 1e9 and "REHEARSAL" not in d["config"]["workload"]
+    st = d["slab_status"]
+    assert st["overflow_on_any_rank"] is False and st["multi_layer_move_on_any_rank"] is False
+    assert st["records_lo_hi_live_per_rank"][0][:2] == [0, 0] and st["records_lo_hi_live_per_rank"][0][2] == 8388608
