@@ -121,7 +121,8 @@ struct SphEngine {
     sph::ShapeTab shapeTab{};
     // boundary-first substep (sph_slab_step_*): the halo exchange of the NEXT substep runs on xstream beside the interior of the SPH pass
     hipStream_t xstream = nullptr;
-    hipEvent_t evBoundary = nullptr, evPacked = nullptr, evDone = nullptr;
+    hipStream_t bstream = nullptr;          // high priority: the SPH pass of the face slots, CONCURRENT with the interior launch on the engine's stream
+    hipEvent_t evBoundary = nullptr, evPacked = nullptr, evDone = nullptr, evSorted = nullptr;
     hipEvent_t peerDone[2] = {nullptr, nullptr};   // evDone of the lower / upper neighbour ENGINE of the last local transfer: it has read this engine's send face
     bool stepPending = false;               // sph_slab_step_begin ran, its finish has not yet
     bool slabOrderValid = false;            // slots are in the order of the last counting sort and no particle can have moved by more than a layer since
@@ -430,12 +431,12 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
         Timed t(e, SPH_K_SPH);
         if (e->optNeighbor == 3 && (size_t)n < ((size_t)1 << 27)) {        // (buffer loads address the sorted copy with 32-bit byte offsets)
             const dim3 grid(8 * ((blocks_for(n, 256) + 7) / 8));
-            auto walk = [&](const uint32_t* lo, const uint32_t* hi) {
+            auto walk = [&](hipStream_t st, const uint32_t* lo, const uint32_t* hi) {
                 if (k.h2 <= 1.0f)
-                    hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, e->stream, k, S, in, out,
+                    hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, st, k, S, in, out,
                                        e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi);
                 else
-                    hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, e->stream, k, S, in, out,
+                    hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, st, k, S, in, out,
                                        e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi);
             };
             // The pack of the next exchange only reads the slots of the three lowest / three highest local cell layers (k_slab_pack,
@@ -446,13 +447,20 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             if (split) {
                 const uint32_t* endLo = e->d_cellStart + 3 * (size_t)(k.gx * k.gy);
                 const uint32_t* startHi = e->d_cellStart + (size_t)(k.gz - 3) * (size_t)(k.gx * k.gy);
-                walk(nullptr, endLo);
-                walk(startHi, nullptr);
-                HIP_TRY(hipEventRecord(e->evBoundary, e->stream));
+                // The two face ranges are small launches (three layers each): on the engine's stream they would run one after
+                // the other in front of the interior, each with its own tail.  They go to a high-priority stream of their own and
+                // the interior starts AT ONCE on the engine's stream: same inputs (the sorted copy), disjoint output slots; the
+                // engine's stream joins at the end of the pass.
+                HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                HIP_TRY(hipStreamWaitEvent(e->bstream, e->evSorted, 0));
+                walk(e->bstream, nullptr, endLo);
+                walk(e->bstream, startHi, nullptr);
+                HIP_TRY(hipEventRecord(e->evBoundary, e->bstream));
                 boundaryFirst = false;                                     // recorded
-                walk(endLo, startHi);
+                walk(e->stream, endLo, startHi);
+                HIP_TRY(hipStreamWaitEvent(e->stream, e->evBoundary, 0));
             } else {
-                walk(nullptr, nullptr);
+                walk(e->stream, nullptr, nullptr);
             }
         } else if (e->optNeighbor >= 2) {
             hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n, SPH_LIST_BLOCK) + 7) / 8)), dim3(SPH_LIST_BLOCK), 0, e->stream, k, S, in, out,
@@ -651,6 +659,7 @@ int sph_destroy(SphEngine* e) {
     if (!e) return SPH_OK;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->xstream) (void)hipStreamSynchronize(e->xstream);
+    if (e->bstream) (void)hipStreamSynchronize(e->bstream);
     free_particle_buffers(e);
     free_grid_buffers(e);
     dev_free(e->d_dbg);
@@ -660,7 +669,8 @@ int sph_destroy(SphEngine* e) {
     for (auto& ev : e->evLive) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->xstream) { (void)hipStreamSynchronize(e->xstream); (void)hipStreamDestroy(e->xstream); }
-    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone}) if (ev) (void)hipEventDestroy(ev);
+    if (e->bstream) { (void)hipStreamSynchronize(e->bstream); (void)hipStreamDestroy(e->bstream); }
+    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone, e->evSorted}) if (ev) (void)hipEventDestroy(ev);
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return SPH_OK;
@@ -1252,6 +1262,12 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
 static int ensure_xstream(SphEngine* e) {
     if (e->xstream) return SPH_OK;
     HIP_TRY(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->bstream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreateWithFlags(&e->evSorted, hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&e->evBoundary, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->evPacked, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->evDone, hipEventDisableTiming));
