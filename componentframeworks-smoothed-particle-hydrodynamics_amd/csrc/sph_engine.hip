@@ -121,8 +121,8 @@ struct SphEngine {
     sph::ShapeTab shapeTab{};
     // boundary-first substep (sph_slab_step_*): the halo exchange of the NEXT substep runs on xstream beside the interior of the SPH pass
     hipStream_t xstream = nullptr;
-    hipStream_t bstream = nullptr;          // high priority: the SPH pass of the face slots, CONCURRENT with the interior launch on the engine's stream
-    hipEvent_t evBoundary = nullptr, evPacked = nullptr, evDone = nullptr, evSorted = nullptr;
+    hipStream_t bstream = nullptr;          // LOW priority: the interior launch of the SPH pass, beside the face launches on the engine's stream and the exchange on xstream
+    hipEvent_t evBoundary = nullptr, evPacked = nullptr, evDone = nullptr, evSorted = nullptr, evInterior = nullptr;
     hipEvent_t peerDone[2] = {nullptr, nullptr};   // evDone of the lower / upper neighbour ENGINE of the last local transfer: it has read this engine's send face
     bool stepPending = false;               // sph_slab_step_begin ran, its finish has not yet
     bool slabOrderValid = false;            // slots are in the order of the last counting sort and no particle can have moved by more than a layer since
@@ -447,18 +447,28 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             if (split) {
                 const uint32_t* endLo = e->d_cellStart + 3 * (size_t)(k.gx * k.gy);
                 const uint32_t* startHi = e->d_cellStart + (size_t)(k.gz - 3) * (size_t)(k.gx * k.gy);
-                // The two face ranges are small launches (three layers each): on the engine's stream they would run one after
-                // the other in front of the interior, each with its own tail.  They go to a high-priority stream of their own and
-                // the interior starts AT ONCE on the engine's stream: same inputs (the sorted copy), disjoint output slots; the
-                // engine's stream joins at the end of the pass.
-                HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                // The two face ranges are small launches (three layers each); alone in front of the interior each would leave the
+                // machine half empty at its tail.  They stay FIRST on the engine's stream -- the exchange behind them needs them
+                // early: the transfer has to fit beside the interior -- and the interior goes to a LOW-priority stream of its own
+                // that starts behind the FIRST face launch: beside the second one and, later, beside the pack / unpack kernels of the
+                // high-priority exchange stream, it fills whatever they leave free.  (Started together with the first face launch it
+                // takes half the machine from both of them and the exchange begins 410 us into the pass instead of 250: measured,
+                // profiles/r03_slab_face_launch_schedules.txt.)  Same inputs, disjoint output slots; the engine's stream joins the
+                // interior at the end of the pass.
+#ifndef SPH_SLAB_INTERIOR_AFTER
+#define SPH_SLAB_INTERIOR_AFTER 1     // 0: the interior starts with the first face launch, 1: after it (beside the second), 2: after both (no overlap)
+#endif
+                if (SPH_SLAB_INTERIOR_AFTER == 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                walk(e->stream, nullptr, endLo);
+                if (SPH_SLAB_INTERIOR_AFTER == 1) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                walk(e->stream, startHi, nullptr);
+                if (SPH_SLAB_INTERIOR_AFTER == 2) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                HIP_TRY(hipEventRecord(e->evBoundary, e->stream));
                 HIP_TRY(hipStreamWaitEvent(e->bstream, e->evSorted, 0));
-                walk(e->bstream, nullptr, endLo);
-                walk(e->bstream, startHi, nullptr);
-                HIP_TRY(hipEventRecord(e->evBoundary, e->bstream));
+                walk(e->bstream, endLo, startHi);
+                HIP_TRY(hipEventRecord(e->evInterior, e->bstream));
                 boundaryFirst = false;                                     // recorded
-                walk(e->stream, endLo, startHi);
-                HIP_TRY(hipStreamWaitEvent(e->stream, e->evBoundary, 0));
+                HIP_TRY(hipStreamWaitEvent(e->stream, e->evInterior, 0));
             } else {
                 walk(e->stream, nullptr, nullptr);
             }
@@ -670,7 +680,7 @@ int sph_destroy(SphEngine* e) {
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->xstream) { (void)hipStreamSynchronize(e->xstream); (void)hipStreamDestroy(e->xstream); }
     if (e->bstream) { (void)hipStreamSynchronize(e->bstream); (void)hipStreamDestroy(e->bstream); }
-    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone, e->evSorted}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone, e->evSorted, e->evInterior}) if (ev) (void)hipEventDestroy(ev);
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return SPH_OK;
@@ -1261,12 +1271,13 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
 // ---- boundary-first substep: the exchange of the next substep beside the interior of this one -------------------------
 static int ensure_xstream(SphEngine* e) {
     if (e->xstream) return SPH_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
     {
-        int least = 0, greatest = 0;
+        int least = 0, greatest = 0;                         // (numerically: greatest <= least)
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&e->bstream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->xstream, hipStreamNonBlocking, greatest));   // pack / transfer / unpack: few small kernels that must not queue behind the interior's blocks
+        HIP_TRY(hipStreamCreateWithPriority(&e->bstream, hipStreamNonBlocking, least));      // the interior of the SPH pass
         HIP_TRY(hipEventCreateWithFlags(&e->evSorted, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->evInterior, hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&e->evBoundary, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->evPacked, hipEventDisableTiming));
