@@ -17,7 +17,7 @@
 #include "sph_host.h"
 #include "sph_kernels.h"
 #include "sph_pass.h"
-#include "sph_walk.h"
+#include "sph_tile.h"
 
 static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
 
@@ -114,6 +114,9 @@ struct SphEngine {
     std::vector<float> terrainHeights;      // CPU copy of the heightfield (:175); empty = river step off (:512)
     float* d_terrain = nullptr;             // terrainSSBO (binding 7 of TerrainConstraints.comp)
     size_t terrainCap = 0;
+    uint8_t* d_tileDone = nullptr;          // k_sph_tile: 1 = this block of cells was done by it (k_sph_walk takes the others)
+    uint32_t* d_nFallback = nullptr;        // blocks of cells left to k_sph_walk in this substep (zeroed by the scan)
+    int tileCap = 0;
     float4 *d_sPV = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state: 32-byte records (pos, 1/rho | vel, P) + own data
     size_t sortedCap = 0;
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
@@ -213,6 +216,7 @@ void free_grid_buffers(SphEngine* e) {
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);   // captured launches hold these addresses
     e->graphs.clear();
     dev_free(e->d_cellCount); dev_free(e->d_cellStart); dev_free(e->d_blockSums);
+    dev_free(e->d_tileDone); dev_free(e->d_nFallback); e->tileCap = 0;
     e->allocatedCells = 0;
 }
 
@@ -250,6 +254,8 @@ int ensure_grid_buffers(SphEngine* e) {
     if ((rc = dev_alloc(&e->d_cellCount, C))) return rc;
     if ((rc = dev_alloc(&e->d_cellStart, C + 1))) return rc;
     if ((rc = dev_alloc(&e->d_blockSums, (size_t)blocks_for(C, kScanTile) + 1))) return rc;
+    if ((rc = dev_alloc(&e->d_tileDone, C)) || (rc = dev_alloc(&e->d_nFallback, (size_t)1))) return rc;   // (one flag per block of cells: <= C)
+    HIP_TRY(hipMemsetAsync(e->d_nFallback, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(hipMemsetAsync(e->d_cellCount, 0, C * sizeof(uint32_t), e->stream));
     e->allocatedCells = want;
     return SPH_OK;
@@ -317,7 +323,7 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     {
         Timed t(e, SPH_K_SCAN);
         hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, C);
-        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kBlock), 0, e->stream, e->d_blockSums, sb);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kBlock), 0, e->stream, e->d_blockSums, sb, e->d_nFallback);
         hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, e->d_cellStart, C, (uint32_t)n);
     }
     if (n) {
@@ -429,15 +435,32 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
         const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
         SortedIn S{e->d_sPV, e->d_sOwn};
         Timed t(e, SPH_K_SPH);
-        if (e->optNeighbor == 3 && (size_t)n < ((size_t)1 << 27)) {        // (buffer loads address the sorted copy with 32-bit byte offsets)
+        if (e->optNeighbor >= 3 && (size_t)n < ((size_t)1 << 27)) {        // (buffer loads address the sorted copy with 32-bit byte offsets)
             const dim3 grid(8 * ((blocks_for(n, 256) + 7) / 8));
+            // k_sph_tile first (single-domain engines): one workgroup per block of cells; k_sph_walk behind it takes what it left
+            const bool tiled = e->optNeighbor == 4 && !e->slab;
+            const TileGeom tg{(k.gx + SPH_TILE_X - 1) / SPH_TILE_X, (k.gy + SPH_TILE_Y - 1) / SPH_TILE_Y, (k.gz + SPH_TILE_Z - 1) / SPH_TILE_Z};
+            const uint8_t* behind = nullptr;
+            if (tiled) {
+                const int nTiles = tg.ntx * tg.nty * tg.ntz;
+                const dim3 tgrid(8 * ((nTiles + 7) / 8));
+                if (k.h2 <= 1.0f)
+                    hipLaunchKernelGGL((k_sph_tile<SPH_TILE_X, SPH_TILE_Y, SPH_TILE_Z, SPH_TILE_WAVES, SPH_TILE_CAP, SPH_TILE_MAXN, SPH_TILE_UNROLL, true>), tgrid,
+                                       dim3(SPH_TILE_WAVES * 64), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, tg, e->d_tileDone, e->d_nFallback,
+                                       e->debugFlags, e->d_stats);
+                else
+                    hipLaunchKernelGGL((k_sph_tile<SPH_TILE_X, SPH_TILE_Y, SPH_TILE_Z, SPH_TILE_WAVES, SPH_TILE_CAP, SPH_TILE_MAXN, SPH_TILE_UNROLL, false>), tgrid,
+                                       dim3(SPH_TILE_WAVES * 64), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, tg, e->d_tileDone, e->d_nFallback,
+                                       e->debugFlags, e->d_stats);
+                behind = e->d_tileDone;
+            }
             auto walk = [&](hipStream_t st, const uint32_t* lo, const uint32_t* hi) {
                 if (k.h2 <= 1.0f)
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi);
+                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg);
                 else
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi);
+                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg);
             };
             // The pack of the next exchange only reads the slots of the three lowest / three highest local cell layers (k_slab_pack,
             // under the same conditions): those two slot ranges first, the event, then everything in between.
@@ -719,7 +742,7 @@ int sph_get_params(const SphEngine* e, SphParams* out) {
 int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
-    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 3) return fail(SPH_ERR_ARG, "SPH pass %d: 3 = k_sph_walk, 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 4) return fail(SPH_ERR_ARG, "SPH pass %d: 4 = k_sph_tile, 3 = k_sph_walk, 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;

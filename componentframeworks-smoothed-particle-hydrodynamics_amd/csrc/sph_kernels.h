@@ -135,8 +135,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restri
 }
 
 // single block: exclusive scan of the per-block sums (any count, chunks of 256 with carry)
-__global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict__ blockSums, int numBlocks) {
+__global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict__ blockSums, int numBlocks, uint32_t* __restrict__ zeroMe) {
     __shared__ uint32_t sm[4];
+    if (zeroMe && threadIdx.x == 0) *zeroMe = 0u;          // k_sph_tile's count of blocks of cells left to k_sph_walk (per substep)
     uint32_t carry = 0;
     for (int base = 0; base < numBlocks; base += kBlock) {
         int i = base + threadIdx.x;

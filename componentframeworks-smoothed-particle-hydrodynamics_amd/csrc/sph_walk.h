@@ -32,11 +32,30 @@ namespace sph {
 #ifndef SPH_WALK_WAVES
 #define SPH_WALK_WAVES 5     // __launch_bounds__ minimum waves per SIMD
 #endif
+#ifndef SPH_WALK_REORDER
+#define SPH_WALK_REORDER 0   // 1: after sweep 1 the block's targets are handed to the lanes in order of their list length (round 4 experiment, bit-exact,
+                             // NOT faster: 446 -> 515 us, profiles/r04_walk_reorder_experiment.txt: a wave of scattered targets gathers from 4x the cache lines)
+#endif
 #ifndef SPH_WALK_EPS
 #define SPH_WALK_EPS 0.04f   // slack of the list around the predicted position, in units of h (0.03 / 0.04 / 0.06 / 0.08: 442 / 441 / 451 / 463 us)
 #endif
 
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+
+// Blocks of cells of k_sph_tile (sph_tile.h).  k_sph_walk runs behind it for the blocks it could not take (tileDone[block] == 0).
+#ifndef SPH_TILE_X
+#define SPH_TILE_X 8
+#endif
+#ifndef SPH_TILE_Y
+#define SPH_TILE_Y 4
+#endif
+#ifndef SPH_TILE_Z
+#define SPH_TILE_Z 4
+#endif
+struct TileGeom { int ntx, nty, ntz; };   // blocks of cells per axis
+__host__ __device__ __forceinline__ int tile_of_cell(int cx, int cy, int cz, const TileGeom& g) {
+    return ((cz / SPH_TILE_Z) * g.nty + cy / SPH_TILE_Y) * g.ntx + cx / SPH_TILE_X;
+}
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byteOff) {
     const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteOff, 0, 0);   // out of range reads return 0, never fault
@@ -81,7 +100,8 @@ template <int MAXN, int UNROLL, int CAP, bool SMALLH>
 __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                                   const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n,
                                                                   int dbg, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ rangeLo,
-                                                                  const uint32_t* __restrict__ rangeHi) {
+                                                                  const uint32_t* __restrict__ rangeHi, const uint8_t* __restrict__ tileDone,
+                                                                  const uint32_t* __restrict__ nFallback, TileGeom tg) {
     constexpr int kB = 256;
     constexpr uint32_t kRowBytes = kB * 2;                 // one list row = one entry of every thread
     static_assert(kRowBytes == 512, "the cursor advance reads bit 9 of (sign >> 22)");
@@ -92,6 +112,7 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     static_assert(CAP <= 192, "the window is staged with three loads per lane, and a window offset has 8 bits in an entry");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    if (tileDone && *nFallback == 0u) return;              // behind k_sph_tile: it took every block of cells
     // XCD-aware block mapping as in k_sph_list: blocks b and b + 8 share an XCD, each XCD walks one contiguous eighth of the LIVE slots.
     // A launch may cover only the slot range [*rangeLo, *rangeHi) (device-side bounds, nullptr = open end): a z-slab engine
     // runs the slots next to its faces first, so that the halo exchange can start while the interior is still being computed.
@@ -111,6 +132,9 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = 0.0f; o.prs = 0.0f;
     const uint32_t cb = fbits(O.x);
     const int cx = (int)(cb & 1023u), cy = (int)((cb >> 10) & 1023u), cz = (int)(cb >> 20);
+    if (tileDone) {                                        // targets of a block of cells that k_sph_tile has done
+        if (live && tileDone[tile_of_cell(cx, cy, cz, tg)]) live = false;
+    }
     const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
     const __amdgpu_buffer_rsrc_t bufPV = __builtin_amdgcn_make_buffer_rsrc((void*)S.pv, 0, (int)((uint32_t)n * 32u), 0x00020000);
     // The list must hold every candidate within h of the ENTRY position (sweep 2) and of the position after this substep's
@@ -243,8 +267,80 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     listOk = (listOk && cur < curEnd) || !live;            // a cursor that reached the end may have dropped entries; lanes without a target never fall back
     finish_density(k, o);
 
+#if SPH_WALK_REORDER
+    // ---- hand the block's 256 targets to the lanes in the order of their list length (round 4) ----
+    // The walks below are per-lane loops: a wave runs to its longest list, and the lists of 64 consecutive targets differ by
+    // +- 2.5 entries around 10 (16 slots for 10.1 entries).  A counting sort over the block by list length (targets without a usable
+    // list last, lanes without a target first) makes the lists of a wave equal to within an entry or two.  Which lane computes a
+    // target changes nothing in its arithmetic.  The windows of sweep 1 are dead by now: their LDS holds the sort's scratch.
+    static_assert(sizeof(float4) * (kB / 64) * CAP >= kB * 16 + 64 * 4, "the sort's scratch lives in the windows");
+    uint32_t* const sHist = reinterpret_cast<uint32_t*>(&stage[0][0]);                // [64] bins: list length (0 .. MAXN), MAXN + 1 = no usable list
+    float2* const sRP = reinterpret_cast<float2*>(sHist + 64);                      // [kB] density / pressure of this substep
+    uint32_t* const sCur = reinterpret_cast<uint32_t*>(sRP + kB);                   // [kB] list end | live << 30 | listOk << 31
+    uint16_t* const sPerm = reinterpret_cast<uint16_t*>(sCur + kB);                 // [kB] target (old thread index) of each lane
+    __syncthreads();                                       // every wave is through its windows
+    if (tid < 64) sHist[tid] = 0u;
+    __syncthreads();
+    const uint32_t key = !live ? 0u : (listOk ? 1u + (cur - (uint32_t)tid * 2u) / kRowBytes : (uint32_t)MAXN + 2u);
+    static_assert(MAXN + 3 <= 64, "bins");
+    const uint32_t inBin = atomicAdd(&sHist[key], 1u);
+    sRP[tid] = make_float2(o.rho, o.prs);
+    sCur[tid] = cur | (live ? 1u << 30 : 0u) | (listOk ? 1u << 31 : 0u);
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t c = sHist[lane];
+        const uint32_t inc = wave_incl_scan(c);
+        sHist[lane] = inc - c;
+    }
+    __syncthreads();
+    sPerm[sHist[key] + inBin] = (uint16_t)tid;
+    __syncthreads();
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 2        // timing experiment only: all the machinery, but every lane keeps its target
+    const int me = ((int)sPerm[tid] & 0) | tid;
+#else
+    const int me = (int)sPerm[tid];
+#endif                        // this lane's target from here on: the one thread `me` took through sweep 1
+    const uint32_t cw = sCur[me];
+    live = (cw >> 30) & 1u;
+    listOk = (cw >> 31) != 0u;
+    cur = cw & 0x3fffffffu;
+    const int sN = live ? first + vb * kB + me : max(bound - 1, 0);
+    const float4 PN = S.P(sN), VN = S.V(sN), ON = S.own[sN];
+    const float2 rpN = sRP[me];
+    own_reset(o);
+    o.px = PN.x; o.py = PN.y; o.pz = PN.z; o.vx = VN.x; o.vy = VN.y; o.vz = VN.z; o.rho = rpN.x; o.prs = rpN.y;
+    const uint32_t cbN = fbits(ON.x);
+    const int cxN = (int)(cbN & 1023u), cyN = (int)((cbN >> 10) & 1023u), czN = (int)(cbN >> 20);
+    const int xloN = max(cxN - 1, 0), xhiN = min(cxN + 1, k.gx - 1);
+    const float qxN = fmaf(0.995f * fmaf(k.gravx, k.dt, o.vx), k.dt, o.px), qyN = fmaf(0.995f * fmaf(k.gravy, k.dt, o.vy), k.dt, o.py),
+                qzN = fmaf(0.995f * fmaf(k.gravz, k.dt, o.vz), k.dt, o.pz);
+#define W_S sN
+#define W_O ON
+#define W_CX cxN
+#define W_CY cyN
+#define W_CZ czN
+#define W_XLO xloN
+#define W_XHI xhiN
+#define W_QX qxN
+#define W_QY qyN
+#define W_QZ qzN
+#define W_ME me
+#else
+#define W_S s
+#define W_O O
+#define W_CX cx
+#define W_CY cy
+#define W_CZ cz
+#define W_XLO xlo
+#define W_XHI xhi
+#define W_QX qx
+#define W_QY qy
+#define W_QZ qz
+#define W_ME tid
+#endif
+
     // ---- walks of sweeps 2 / 3: per-lane loops over the list; the 32-byte records of the next two entries are in flight ----
-    const char* const rowBytes = reinterpret_cast<const char*>(&rowA[wv][0]);
+    const char* const rowBytes = reinterpret_cast<const char*>(&rowA[W_ME >> 6][0]);
     auto fetch = [&](uint32_t at, float4& J, float4& JV) {
         const uint32_t ent = *reinterpret_cast<const uint16_t*>(nlBytes + at);
         const uint32_t base = *reinterpret_cast<const uint32_t*>(rowBytes + ((ent >> 10) & 0x3cu));
@@ -259,7 +355,7 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         // The pass is bound by the cache lines its gathers touch in L1 (profiles/r03_walk_mem_counters.log: ~0.9 tag lookups per
         // cycle and CU), so a look-ahead load is issued only for an entry that exists: no lane ever fetches past its list.
         const uint32_t end = cur;                          // <= curEnd - kRowBytes here
-        uint32_t at = (uint32_t)tid * 2u;
+        uint32_t at = (uint32_t)W_ME * 2u;
         float4 J0, V0, J1, V1, J2, V2, J3, V3;
         J0 = V0 = J1 = V1 = J2 = V2 = J3 = V3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (at < end) fetch(at, J0, V0);
@@ -282,19 +378,19 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     // Exact fallback of a sweep for lanes whose list cannot be used: every candidate again, in canonical order, from global memory.
     auto plain = [&](auto&& f) {
         for (int r = 0; r < 9; ++r) {
-            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
+            const int nz = W_CZ + r / 3 - 1, ny = W_CY + r % 3 - 1;
             if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
             const int rowBase = (nz * k.gy + ny) * k.gx;
-            const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
+            const uint32_t a = cellStart[rowBase + W_XLO], b = cellStart[rowBase + W_XHI + 1];
             // (a candidate outside h of every lane that is here adds +-0 everywhere: the wave skips its pair arithmetic)
             auto within = [&](const float4& J) { const float dx = o.px - J.x, dy = o.py - J.y, dz = o.pz - J.z; return dot3(dx, dy, dz, dx, dy, dz) < k.h2; };
             uint32_t q = a;
             for (; q + 2u <= b; q += 2u) {                    // two candidates' loads in flight (in compressed fluid they are broadcasts: the wave's targets share their candidates)
                 const float4 J0 = S.P(q), V0 = S.V(q), J1 = S.P(q + 1u), V1 = S.V(q + 1u);
-                if (__any(within(J0))) f(J0, V0, (int32_t)((int)q != s ? -1 : 0));
-                if (__any(within(J1))) f(J1, V1, (int32_t)((int)(q + 1u) != s ? -1 : 0));
+                if (__any(within(J0))) f(J0, V0, (int32_t)((int)q != W_S ? -1 : 0));
+                if (__any(within(J1))) f(J1, V1, (int32_t)((int)(q + 1u) != W_S ? -1 : 0));
             }
-            if (q < b) { const float4 J = S.P(q); if (__any(within(J))) f(J, S.V(q), (int32_t)((int)q != s ? -1 : 0)); }
+            if (q < b) { const float4 J = S.P(q); if (__any(within(J))) f(J, S.V(q), (int32_t)((int)q != W_S ? -1 : 0)); }
         }
     };
     auto force_at = [&](const float4& J, const float4& JV) { pair_force_other(k, o, J, JV); };
@@ -302,30 +398,41 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     auto force_plain = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
     auto xsph_plain = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
 #if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 1   // timing experiment only: stop after sweep 1
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cur, o.ay, o.az, o.rho, o.prs, O.y, cz);
+    if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cur, o.ay, o.az, o.rho, o.prs, W_O.y, W_CZ);
     return;
 #endif
     // ---- sweep 2 ----
     if (listOk) listed(force_at); else plain(force_plain);
     integrate(k, o);
 #if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 2   // timing experiment only: stop after sweep 2
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, O.y, cz);
+    if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, W_O.y, W_CZ);
     return;
 #endif
     // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
-    const float mx = o.px - qx, my = o.py - qy, mz = o.pz - qz;
+    const float mx = o.px - W_QX, my = o.py - W_QY, mz = o.pz - W_QZ;
     const float lim = 0.98f * eps;
     const bool near = (dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2)) || !live;
     if (listOk && near) listed(xsph_at); else plain(xsph_plain);
-    const float foamOut = finish_particle(k, o, O.y);
-    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, cz);
+    const float foamOut = finish_particle(k, o, W_O.y);
+    if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, W_CZ);
     if (dbg & 8) {   // diagnostics: [0] candidate rows walked from global memory (window too large), [3] candidate rows, [1] targets on an exact fallback sweep, [2] list entries, [4] lanes, [5] overflowed lists, [6] far targets, [7] waves with a fallback
         const unsigned long long slowT = (unsigned long long)__popcll(__ballot(live && !(listOk && near)));
-        unsigned long long ents = (unsigned long long)((live && listOk) ? (cur - (uint32_t)tid * 2u) / kRowBytes : 0u);
+        unsigned long long ents = (unsigned long long)((live && listOk) ? (cur - (uint32_t)W_ME * 2u) / kRowBytes : 0u);
         for (int d = 32; d >= 1; d >>= 1) ents += (unsigned long long)__shfl_xor((int)ents, d, 64);
         const unsigned long long ovf = (unsigned long long)__popcll(__ballot(live && !listOk)), far = (unsigned long long)__popcll(__ballot(live && listOk && !near));
         if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)nUnstaged); atomicAdd(&stats[3], (unsigned long long)nRows); atomicAdd(&stats[1], slowT); atomicAdd(&stats[2], ents & 0xffffffffull); atomicAdd(&stats[4], 64ull); atomicAdd(&stats[5], ovf); atomicAdd(&stats[6], far); atomicAdd(&stats[7], slowT ? 1ull : 0ull); }
     }
 }
+#undef W_S
+#undef W_O
+#undef W_CX
+#undef W_CY
+#undef W_CZ
+#undef W_XLO
+#undef W_XHI
+#undef W_QX
+#undef W_QY
+#undef W_QZ
+#undef W_ME
 
 }  // namespace sph
