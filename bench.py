@@ -203,6 +203,15 @@ def main():
         if frame and wave["n"] % frame == 0:
             present()
 
+    # N > 1: the transport's health before anything is timed (one grouped ncclSend + ncclRecv of a face-sized message from the rank
+    # to itself: the only send / receive a one-GPU box can execute; on a node it still says that RCCL moves bytes on this rank)
+    selftest_gbs = None
+    if multi and backend == "nccl" and isinstance(sim.exchange, halo.RcclComm):
+        try:
+            sim.exchange.selftest_gbs(1 << 20)
+            selftest_gbs = round(sim.exchange.selftest_gbs(int(sim.engine.message_bytes()[2] or sim.engine.message_bytes()[3] or (1 << 24)) & ~3), 1)
+        except Exception as ex:                              # noqa: BLE001
+            print(f"[rank {rank}] RCCL self-test failed: {ex}", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     sim.set_option(pkg.SPH_OPT_TIMING, 2)          # hipEvents around the dominant kernel only
@@ -293,15 +302,41 @@ def main():
         aos_eager = {"value": n_total * args.steps / te, "ms_per_step": round(te / args.steps * 1e3, 4), "sph_pass_us": round(ems / max(ecnt, 1) * 1e3, 1),
                      "note": "same workload, warm-up and window with SPH_OPT_AOS_MODE 0 (the SPH pass also updates every 80-byte record), fresh engine, not the headline"}
 
+    # z-slab runs, untimed for `value`: where the exchange of a boundary-first step sat relative to the SPH pass, per rank (hipEvents on the
+    # exchange stream and on the engine's stream): pack -> transfer -> unpack, the end of the exchange and the end of the pass measured from
+    # the step's start.  The transfer was hidden behind the interior iff exchange_end <= pass_end; sent bytes / transfer ms = the link's rate.
+    exchange_diag = None
+    if multi and backend == "nccl" and isinstance(sim.exchange, halo.RcclComm) and getattr(sim, "overlap", False):
+        sim.set_option(pkg.SPH_OPT_TIMING, 1)
+        acc = [0.0] * 5
+        nd = 5
+        for _ in range(nd):
+            step()
+            for i, v in enumerate(sim.engine.step_times()):
+                acc[i] += v / nd
+        sim.kernel_times(reset=True)
+        sim.set_option(pkg.SPH_OPT_TIMING, 0)
+        mb = sim.engine.message_bytes()
+        mine = acc + [float(v) for v in mb]
+        tst = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(tst) for _ in range(world)]
+        dist.all_gather(gathered, tst)
+        exchange_diag = {"per_rank": [{"pack_ms": round(g[0].item(), 4), "transfer_ms": round(g[1].item(), 4), "unpack_ms": round(g[2].item(), 4),
+                                       "exchange_end_ms": round(g[3].item(), 4), "pass_end_ms": round(g[4].item(), 4),
+                                       "hidden_behind_the_pass": bool(g[3].item() <= g[4].item()),
+                                       "sent_bytes_lo_hi": [int(g[5].item()), int(g[6].item())], "face_bytes": int(max(g[7].item(), g[8].item()))} for g in gathered],
+                         "substeps_averaged": nd, "rccl_selftest_gbs": selftest_gbs,
+                         "note": "hipEvents of the last boundary-first steps, untimed for value; halo copies travel as 40-byte records, messages are sized from the counts of two exchanges ago"}
+
     # z-slab runs: overflow of a face buffer or of the slot capacity is flagged on the device, never fatal in the
     # substep loop; a run that dropped records is not a measurement, so every rank's flags go into the line.
     slab_status = None
     if multi:
         try:
             st = sim.engine.status()
-            mine = [int(st[0]), int(st[1]), int(st[2]), 0]
+            mine = [int(st[0]), int(st[1]), int(st[2]), 2 if int(st[4]) & 16 else 0]
         except Exception as ex:                          # noqa: BLE001  (SphError: the status call reports an overflow as an error)
-            mine = [0, 0, 0, 2 if "more than one cell layer" in str(ex) else 1]
+            mine = [0, 0, 0, 1]
             print(f"[rank {rank}] slab status: {ex}", file=sys.stderr, flush=True)
         tst = torch.tensor(mine, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         gathered = [torch.zeros_like(tst) for _ in range(world)]
@@ -382,6 +417,7 @@ def main():
         },
         "kernels_us_per_substep": breakdown,
         "slab_status": slab_status,
+        "exchange": exchange_diag,
         "aos_eager": aos_eager,
         "settled": settled,
         "valu": valu,

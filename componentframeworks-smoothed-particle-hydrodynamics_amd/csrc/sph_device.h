@@ -64,18 +64,21 @@ __device__ __forceinline__ int cell_z_global(const SimK& k, float pz) { return c
 __device__ __forceinline__ int cell_z_local(const SimK& k, float pz) {
     return min(max(cell_z_global(k, pz) - k.zoff, 0), k.gz - 1);
 }
-// z-slab engines.  The exchange is built on ONE assumption: a substep moves a particle across at most one cell layer in z (halo
-// copies are one layer deep, migrants go to the adjacent rank, and while the container stays put the pack looks only at the slots of
-// the three lowest / three highest local layers).  SPHFluid.comp integrates the position with the UNCAPPED velocity (v + a dt) and
+// z-slab engines.  Round 4: the exchange FOLLOWS a particle across up to kSlabJump cell layers in z per substep (halo copies are one layer
+// deep and migrants go to the adjacent rank -- which a jump of up to kSlabJump layers still reaches while every slab is thicker than
+// that -- and while the container stays put the pack looks only at the slots of the kSlabDepth = kSlabJump + 2 lowest / highest local layers:
+// whatever ends in a face layer or beyond it began the substep there).  SPHFluid.comp integrates the position with the UNCAPPED velocity (v + a dt) and
 // OBBConstraints.comp projects, so a violent substep can do more.  Where that makes the decomposed run differ from the single-domain
 // run it is REPORTED (error bit 16 of the exchange's flags), not followed:
 //   * here, for the pack's reduced scan: a particle that began the substep OUTSIDE the slot ranges the next pack reads and ends in a
 //     layer that pack would have acted on (a face layer: halo copy; beyond it: migrant);
 //   * in k_slab_unpack*, for migrants that land on a rank that cannot place them (slab_record_misplaced).
 // k.slabFlags is set only for substeps whose following pack may use the reduced scan.
+constexpr int kSlabJump = 3;                  // cell layers in z a substep may carry a particle across and still be followed exactly
+constexpr int kSlabDepth = kSlabJump + 2;     // local layers (ghost layer included) at each end of a slab that the pack and the face launches cover
 __device__ __forceinline__ void slab_check_layer_move(const SimK& k, int czEntryLocal, float pzNew) {
     if (!k.slabFlags) return;                                      // (kernel-uniform)
-    if (czEntryLocal < 3 || czEntryLocal > k.gz - 4) return;       // the pack reads this slot anyway
+    if (czEntryLocal < kSlabDepth || czEntryLocal > k.gz - kSlabDepth - 1) return;       // the pack reads this slot anyway
     // half a cell of margin around the exact test, so that nearly every particle leaves after two comparisons
     const float zLo = fmaf((float)(k.zoff + 2) + 0.5f, k.cellSize, k.gminz), zHi = fmaf((float)(k.zoff + k.gz - 2) - 0.5f, k.cellSize, k.gminz);
     if (pzNew > zLo && pzNew < zHi) return;

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,9 @@ inline int blocks_for(size_t n, int per = sph::kBlock) { return (int)((n + per -
 
 }  // namespace
 
+struct SphEngine;
+static std::set<SphEngine*> g_engines;      // live engines of this process (sph_destroy clears what neighbours hold of a destroyed one)
+
 struct SphEngine {
     hipStream_t stream = nullptr;
     bool ownStream = false;
@@ -106,7 +110,22 @@ struct SphEngine {
     bool slab = false;
     int z0 = 0, z1 = 0, hasLo = 0, hasHi = 0;
     size_t nSlots = 0;                      // state slots in use (live + dead), upper bound of the live count (= cap once the async exchange is used)
-    sph::SlabRec* d_face[4] = {nullptr, nullptr, nullptr, nullptr};   // engine-owned halo buffers: send lo / hi, recv lo / hi ((faceCap + 1) records, record 0 = header)
+    char* d_face[4] = {nullptr, nullptr, nullptr, nullptr};   // engine-owned halo buffers: send lo / hi, recv lo / hi (sph::slab_face_bytes(faceCap): header, migrants, halo copies)
+    // message sizing (round 4): the two messages per direction carry the records in use, sized from the counts of TWO exchanges ago
+    // (read back asynchronously into pinned memory; both ends of a link see the same numbers: the sender its own count, the receiver the
+    // header it got), the face capacity until those exist
+    uint32_t* h_cnt = nullptr;              // pinned, 4 slots x 8 words: own halo lo / hi, own migrants lo / hi, received (halo, migrants) from lo, from hi
+    hipEvent_t evCnt[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool cntValid[4] = {false, false, false, false};
+    uint32_t exchangeNo = 0;                // sized exchanges enqueued so far
+    uint32_t msgSend[4] = {0, 0, 0, 0}, msgRecv[4] = {0, 0, 0, 0};   // records of the exchange being enqueued: halo lo / hi, migrants lo / hi
+    uint64_t sentBytes[2] = {0, 0};         // bytes of the last exchange's messages to lo / hi
+    uint32_t stepNo = 0;                    // boundary-first steps begun
+    bool stepPaused = false;                // the pending step is a paused one (nothing was enqueued)
+    float packGrid[8] = {0};                // grid (gridMin, cellSize, dims) the halo records in place were cut for
+    bool packGridValid = false;
+    hipEvent_t evX[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // SPH_OPT_TIMING: pass start, pack start, pack end, transfer end, unpack end of the last step
+    hipEvent_t evPassEnd = nullptr;         // SPH_OPT_TIMING: end of the SPH pass (interior included) of the last boundary-first step
     uint32_t faceCap = 0;
     const void* faceAgreedWith = nullptr;   // communicator whose ranks were checked to share faceCap (sph_slab_exchange)
     SphFountain fountain{};                 // fountain* members (SPHFluid3D.h:161-168)
@@ -235,7 +254,8 @@ int alloc_particle_buffers(SphEngine* e, size_t n) {
     if ((rc = dev_alloc(&e->d_slotOf, n))) return rc;
     if ((rc = dev_alloc(&e->d_order, n))) return rc;
     if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
-    if ((rc = dev_alloc(&e->d_slabCnt, 8))) return rc;
+    if ((rc = dev_alloc(&e->d_slabCnt, 16))) return rc;
+    HIP_TRY(hipMemsetAsync(e->d_slabCnt, 0, 16 * sizeof(uint32_t), e->stream));
     e->cap = n;
     return SPH_OK;
 }
@@ -462,14 +482,15 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, st, k, S, in, out,
                                        e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg);
             };
-            // The pack of the next exchange only reads the slots of the three lowest / three highest local cell layers (k_slab_pack,
+            // The pack of the next exchange only reads the slots of the kSlabDepth lowest / highest local cell layers (k_slab_pack,
             // under the same conditions): those two slot ranges first, the event, then everything in between.
             float contNow[15];
             container_key(e->params, contNow);
-            const bool split = boundaryFirst && e->slab && k.gz > 6 && !k.obbDeferred && std::memcmp(contNow, e->lastContainer, sizeof(contNow)) == 0;
+            const bool split = boundaryFirst && e->slab && k.gz > 2 * kSlabDepth && !k.obbDeferred && std::memcmp(contNow, e->lastContainer, sizeof(contNow)) == 0;
+            const bool timedStep = boundaryFirst && e->optTiming && e->evPassEnd;
             if (split) {
-                const uint32_t* endLo = e->d_cellStart + 3 * (size_t)(k.gx * k.gy);
-                const uint32_t* startHi = e->d_cellStart + (size_t)(k.gz - 3) * (size_t)(k.gx * k.gy);
+                const uint32_t* endLo = e->d_cellStart + kSlabDepth * (size_t)(k.gx * k.gy);
+                const uint32_t* startHi = e->d_cellStart + (size_t)(k.gz - kSlabDepth) * (size_t)(k.gx * k.gy);
                 // The two face ranges are small launches (three layers each); alone in front of the interior each would leave the
                 // machine half empty at its tail.  They stay FIRST on the engine's stream -- the exchange behind them needs them
                 // early: the transfer has to fit beside the interior -- and the interior goes to a LOW-priority stream of its own
@@ -495,6 +516,7 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             } else {
                 walk(e->stream, nullptr, nullptr);
             }
+            if (timedStep) HIP_TRY(hipEventRecord(e->evPassEnd, e->stream));
         } else if (e->optNeighbor >= 2) {
             hipLaunchKernelGGL((k_sph_list<SPH_LIST_MAXN, SPH_LIST_UNROLL, SPH_LIST_CAP>), dim3(8 * ((blocks_for(n, SPH_LIST_BLOCK) + 7) / 8)), dim3(SPH_LIST_BLOCK), 0, e->stream, k, S, in, out,
                                e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats);
@@ -585,7 +607,8 @@ int slab_flags_error(const SphEngine* e, uint32_t flags, uint32_t nLo, uint32_t 
     if (flags & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
     if (flags & 4u) return fail(SPH_ERR_HIP, "a received halo message did not start with a valid header (magic / count): failed or garbled receive");
     if (flags & 8u) return fail(SPH_ERR_CAPACITY, "a neighbour rank had more halo records than its message could carry (face capacity %u)", e->faceCap);
-    if (flags & 16u) return fail(SPH_ERR_STATE, "a particle crossed more than one cell layer in z within one substep (placed outside the container, or a container that moved by cells): the slab decomposition no longer equals the single-domain run");
+    // (flag 16 -- a particle crossed more cell layers in z within one substep than the exchange follows -- loses nothing: it is a notice
+    //  that the decomposed run no longer equals the single-domain run, carried by sph_slab_status's out[4], cleared by sph_slab_clear_flags)
     return SPH_OK;
 }
 
@@ -660,6 +683,7 @@ static int create_common(SphEngine** out, const SphParams* params, void* stream,
         e->ownStream = true;
     }
     *made = e;
+    g_engines.insert(e);
     return SPH_OK;
 }
 
@@ -703,7 +727,13 @@ int sph_destroy(SphEngine* e) {
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->xstream) { (void)hipStreamSynchronize(e->xstream); (void)hipStreamDestroy(e->xstream); }
     if (e->bstream) { (void)hipStreamSynchronize(e->bstream); (void)hipStreamDestroy(e->bstream); }
-    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone, e->evSorted, e->evInterior}) if (ev) (void)hipEventDestroy(ev);
+    for (SphEngine* o : g_engines)                                            // a neighbour engine of this process must not wait for an event that is gone
+        for (auto& pd : o->peerDone) if (pd && pd == e->evDone) pd = nullptr;
+    g_engines.erase(e);
+    for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone, e->evSorted, e->evInterior, e->evPassEnd}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->evX) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->evCnt) if (ev) (void)hipEventDestroy(ev);
+    if (e->h_cnt) (void)hipHostFree(e->h_cnt);
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return SPH_OK;
@@ -1135,7 +1165,7 @@ int sph_create_slab(SphEngine** out, const SphParticle* particles, const uint32_
         if (er != hipSuccess) return cleanup(fail(SPH_ERR_HIP, "upload failed: %s", hipGetErrorString(er)));
         hipLaunchKernelGGL(k_slab_import, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, e->d_aos, d_ids, e->d_pos[0], e->d_vel[0], e->d_rp[0], e->d_foam[0], (int)n);
     }
-    const uint32_t init[8] = {0u, 0u, (uint32_t)n, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t init[16] = {0u, 0u, (uint32_t)n, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     hipError_t er = hipMemcpyAsync(e->d_slabCnt, init, sizeof(init), hipMemcpyHostToDevice, e->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
     if (er != hipSuccess) return cleanup(fail(SPH_ERR_HIP, "slab init failed: %s", hipGetErrorString(er)));
@@ -1159,7 +1189,7 @@ int sph_slab_pack(SphEngine* e, void* sendLo, void* sendHi, uint32_t capLo, uint
     // slots that hold data, so no host round trip is needed before the launch
     if (e->nSlots) {
         Timed t(e, SPH_K_OTHER);
-        hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->nSlots)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
+        hipLaunchKernelGGL((k_slab_pack<false>), dim3(blocks_for(e->nSlots)), dim3(kBlock), 0, e->stream, k, e->z0, e->z1, e->hasLo, e->hasHi,
                            e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->accValid ? e->d_acc : (const float4*)nullptr, (int)e->nSlots,
                            (SlabRec*)sendLo, (SlabRec*)sendHi, capLo, capHi, e->d_slabCnt,
                            slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
@@ -1204,8 +1234,10 @@ int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nO
     uint32_t cnts[8] = {0};
     HIP_TRY(hipMemcpyAsync(cnts, e->d_slabCnt, sizeof(cnts), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    // a face or slot overflow dropped records: the owned set would come back short without a word
-    int frc = slab_flags_error(e, cnts[4], cnts[0] + cnts[5], cnts[1] + cnts[6]);
+    if (e->xstream) HIP_TRY(hipStreamSynchronize(e->xstream));
+    // a face or slot overflow dropped records: the owned set would come back short without a word.  (Flag 16 -- a particle crossed
+    // more layers than the exchange follows -- drops nothing: the records are delivered, sph_slab_status carries the notice.)
+    int frc = slab_flags_error(e, cnts[4], cnts[5], cnts[6]);
     if (frc) return frc;
     const size_t n = cnts[2];
     SlabOut* d_out = nullptr;
@@ -1236,9 +1268,14 @@ int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap) {
     int rc;
     for (int i = 0; i < 4; ++i) {
         dev_free(e->d_face[i]);
-        if ((rc = dev_alloc(&e->d_face[i], (size_t)faceCap + 1))) return rc;
-        HIP_TRY(hipMemsetAsync(e->d_face[i], 0, sizeof(SlabRec), e->stream));      // empty header
+        if ((rc = dev_alloc(&e->d_face[i], slab_face_bytes(faceCap)))) return rc;
+        HIP_TRY(hipMemsetAsync(e->d_face[i], 0, sizeof(SlabHdr), e->stream));      // no header yet
     }
+    if (!e->h_cnt) {
+        HIP_TRY(hipHostMalloc((void**)&e->h_cnt, 4 * 8 * sizeof(uint32_t), hipHostMallocDefault));
+        for (auto& ev : e->evCnt) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    for (auto& v : e->cntValid) v = false;
     e->faceCap = faceCap;
     e->faceAgreedWith = nullptr;
     return SPH_OK;
@@ -1249,46 +1286,98 @@ int sph_slab_face_buffer(SphEngine* e, int which, void** devPtr) {
     *devPtr = e->d_face[which];
     return SPH_OK;
 }
+int sph_slab_face_bytes(SphEngine* e, uint64_t* bytes) {
+    if (!e || !bytes) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->faceCap) return fail(SPH_ERR_STATE, "no face buffers: call sph_slab_alloc_faces first");
+    *bytes = (uint64_t)slab_face_bytes(e->faceCap);
+    return SPH_OK;
+}
+static void grid_key(const SphGridInfo& g, float out[8]) {
+    const float v[8] = {g.gridMin[0], g.gridMin[1], g.gridMin[2], g.cellSize, (float)g.dims[0], (float)g.dims[1], (float)g.dims[2], 0.0f};
+    std::memcpy(out, v, sizeof(v));
+}
 static int slab_pack_on(SphEngine* e, hipStream_t st) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     if (!e->slab || !e->d_face[0]) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
     sph::compute_grid_extents(e->params, e->grid);
     SimK k;
     make_simk(e->params, e->grid, e->params.param_timeStep, k);
+    grid_key(e->grid, e->packGrid);                         // the records this pack cuts are classified for THIS grid (sph_slab_step_begin checks it)
+    e->packGridValid = true;
     e->nSlots = e->cap;                                     // from now on only a launch bound: slabCnt[2] counts the slots in use
-    {                                                       // (slabCnt[0..1] are zero: set at creation, reset by k_slab_headers)
+    {                                                       // (slabCnt[8..11] are zero: set at creation, reset by k_slab_headers2)
         Timed t(e, SPH_K_OTHER, st);
-        hipLaunchKernelGGL(k_slab_pack, dim3(blocks_for(e->cap)), dim3(kBlock), 0, st, k, e->z0, e->z1, e->hasLo, e->hasHi,
+        hipLaunchKernelGGL((k_slab_pack<true>), dim3(blocks_for(e->cap)), dim3(kBlock), 0, st, k, e->z0, e->z1, e->hasLo, e->hasHi,
                            e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->accValid ? e->d_acc : (const float4*)nullptr, (int)e->cap,
-                           e->d_face[0] + 1, e->d_face[1] + 1, e->faceCap, e->faceCap, e->d_slabCnt,
+                           (SlabRec*)e->d_face[0], (SlabRec*)e->d_face[1], e->faceCap, e->faceCap, e->d_slabCnt,
                            slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
-        hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, st, e->d_slabCnt, e->hasLo ? e->d_face[0] : (SlabRec*)nullptr,
-                           e->hasHi ? e->d_face[1] : (SlabRec*)nullptr, e->faceCap, e->faceCap);
+        hipLaunchKernelGGL(k_slab_headers2, dim3(1), dim3(1), 0, st, e->d_slabCnt, e->hasLo ? e->d_face[0] : (char*)nullptr,
+                           e->hasHi ? e->d_face[1] : (char*)nullptr, e->faceCap);
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
 }
-static int slab_unpack_on(SphEngine* e, hipStream_t st, const void* recvLo, const void* recvHi, uint32_t recvCap) {
+// msg[4]: records the messages carried (halo lo / hi, migrants lo / hi); the face capacity when whole faces were moved
+static int slab_unpack_on(SphEngine* e, hipStream_t st, const void* recvLo, const void* recvHi, uint32_t recvCap, const uint32_t msg[4]) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
-    const SlabRec* lo = e->hasLo ? (const SlabRec*)recvLo : nullptr;
-    const SlabRec* hi = e->hasHi ? (const SlabRec*)recvHi : nullptr;
+    if (recvCap != e->faceCap || !e->faceCap) return fail(SPH_ERR_ARG, "received faces must have this engine's face capacity (%u, got %u)", e->faceCap, recvCap);
+    const char* lo = e->hasLo ? (const char*)recvLo : nullptr;
+    const char* hi = e->hasHi ? (const char*)recvHi : nullptr;
     if ((e->hasLo && !lo) || (e->hasHi && !hi)) return fail(SPH_ERR_ARG, "missing receive buffer");
     const int c = e->cur;
     e->nSlots = e->cap;
     const SlabGeom geom = slab_geom(e);
     Timed t(e, SPH_K_OTHER, st);
-    if (lo) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, st, lo, (const SlabRec*)nullptr, recvCap,
+    if (lo) hipLaunchKernelGGL(k_slab_unpack2, dim3(blocks_for((size_t)msg[0] + msg[2])), dim3(kBlock), 0, st, lo, (const char*)nullptr, recvCap, msg[0], msg[2], 0u, 0u,
                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap, geom, 1);
-    if (hi) hipLaunchKernelGGL(k_slab_unpack_dev, dim3(blocks_for(recvCap)), dim3(kBlock), 0, st, hi, lo, recvCap,
+    if (hi) hipLaunchKernelGGL(k_slab_unpack2, dim3(blocks_for((size_t)msg[1] + msg[3])), dim3(kBlock), 0, st, hi, lo, recvCap, msg[1], msg[3], msg[0], msg[2],
                                e->d_pos[c], e->d_vel[c], e->d_rp[c], e->d_foam[c], e->d_acc, e->d_slabCnt, (uint32_t)e->cap, geom, 0);
-    hipLaunchKernelGGL(k_slab_commit, dim3(1), dim3(1), 0, st, e->d_slabCnt, lo, hi, (uint32_t)e->cap, recvCap);
+    hipLaunchKernelGGL(k_slab_commit2, dim3(1), dim3(1), 0, st, e->d_slabCnt, lo, hi, recvCap, (uint32_t)e->cap, msg[0], msg[2], msg[1], msg[3]);
     HIP_TRY(hipGetLastError());
     return SPH_OK;
 }
 int sph_slab_pack_async(SphEngine* e) { return e ? slab_pack_on(e, e->stream) : fail(SPH_ERR_ARG, "null engine"); }
 int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap) {
-    return e ? slab_unpack_on(e, e->stream, recvLo, recvHi, recvCap) : fail(SPH_ERR_ARG, "null engine");
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    const uint32_t whole[4] = {e->faceCap, e->faceCap, e->faceCap, e->faceCap};
+    return slab_unpack_on(e, e->stream, recvLo, recvHi, recvCap, whole);
+}
+
+// ---- message sizes: records in use two exchanges ago + a quarter + 1024, the face capacity until those counts exist ----
+static uint32_t msg_records(uint32_t seen, uint32_t cap) { return (uint32_t)std::min<uint64_t>(cap, (uint64_t)seen + seen / 4u + 1024u); }
+static int slab_size_messages(SphEngine* e) {
+    for (int i = 0; i < 4; ++i) e->msgSend[i] = e->msgRecv[i] = e->faceCap;
+    if (e->exchangeNo >= 2) {
+        const int slot = (int)((e->exchangeNo - 2u) & 3u);
+        if (e->cntValid[slot]) {
+            HIP_TRY(hipEventSynchronize(e->evCnt[slot]));   // two exchanges back: long done unless the host is that far ahead of the device
+            const uint32_t* c = e->h_cnt + 8 * slot;
+            for (int i = 0; i < 4; ++i) e->msgSend[i] = msg_records(c[i], e->faceCap);
+            e->msgRecv[0] = msg_records(c[4], e->faceCap); e->msgRecv[2] = msg_records(c[5], e->faceCap);   // from lo: its halo copies, its migrants
+            e->msgRecv[1] = msg_records(c[6], e->faceCap); e->msgRecv[3] = msg_records(c[7], e->faceCap);   // from hi
+        }
+    }
+    e->sentBytes[0] = e->hasLo ? sizeof(SlabHdr) + (uint64_t)e->msgSend[2] * 64u + (uint64_t)e->msgSend[0] * 40u : 0u;
+    e->sentBytes[1] = e->hasHi ? sizeof(SlabHdr) + (uint64_t)e->msgSend[3] * 64u + (uint64_t)e->msgSend[1] * 40u : 0u;
+    return SPH_OK;
+}
+// behind the transfer on `st`: this exchange's true counts (own: slabCnt[12..15]; the neighbours': their headers) on their way to the host
+static int slab_note_counts(SphEngine* e, hipStream_t st) {
+    const int slot = (int)(e->exchangeNo & 3u);
+    uint32_t* c = e->h_cnt + 8 * slot;
+    HIP_TRY(hipMemcpyAsync(c, e->d_slabCnt + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    for (int d = 0; d < 2; ++d) {
+        c[4 + 2 * d] = c[5 + 2 * d] = 0u;
+        if (d ? e->hasHi : e->hasLo) {                      // SlabHdr words: [2] nHaloTrue, [4] nMigTrue
+            HIP_TRY(hipMemcpyAsync(c + 4 + 2 * d, e->d_face[2 + d] + 2 * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(c + 5 + 2 * d, e->d_face[2 + d] + 4 * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIP_TRY(hipEventRecord(e->evCnt[slot], st));
+    e->cntValid[slot] = true;
+    e->exchangeNo += 1u;
+    return SPH_OK;
 }
 
 // ---- boundary-first substep: the exchange of the next substep beside the interior of this one -------------------------
@@ -1304,7 +1393,9 @@ static int ensure_xstream(SphEngine* e) {
     }
     HIP_TRY(hipEventCreateWithFlags(&e->evBoundary, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->evPacked, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&e->evDone, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&e->evDone));                    // (timed: sph_slab_step_times reads it as the end of the exchange)
+    for (auto& ev : e->evX) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipEventCreate(&e->evPassEnd));
     return SPH_OK;
 }
 int sph_slab_step_begin(SphEngine* e, float overrideDt) {
@@ -1313,16 +1404,37 @@ int sph_slab_step_begin(SphEngine* e, float overrideDt) {
     if (e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_begin twice without sph_slab_step_finish / sph_slab_step_finish_local");
     int rc;
     if ((rc = ensure_xstream(e))) return rc;
+    if (e->params.param_pause) {                             // SPHFluid3D.cpp:432: a paused DispatchCompute is a no-op, and so is its exchange --
+        e->stepPending = true; e->stepPaused = true;         // the halo records in place stay valid (impulses act on the copies as on their owners)
+        e->stepNo += 1u;
+        return SPH_OK;
+    }
+    // The halo records in place were cut by the last pack for the grid of THAT moment; a member that moves the grid (box centre / half /
+    // Euler angles, h, grid_cap) must not change between two steps: the records would be classified for the old grid without a word.
+    if (e->packGridValid) {
+        SphGridInfo g;
+        sph::compute_grid_extents(e->params, g);
+        float now[8];
+        grid_key(g, now);
+        if (std::memcmp(now, e->packGrid, sizeof(now)) != 0)
+            return fail(SPH_ERR_STATE, "the grid changed since the halo records in place were cut (box centre / half / angles, h or grid_cap edited between two steps): "
+                                       "prime again with sph_slab_exchange (or pack_async / unpack_async on every engine) before the next sph_slab_step_begin");
+    }
+    if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[0], e->stream));
+    e->stepNo += 1u;
     if ((rc = dispatch_one(e, overrideDt, true))) return rc;               // ... -> SPH (faces first, e->evBoundary, interior) on the engine's stream
     HIP_TRY(hipStreamWaitEvent(e->xstream, e->evBoundary, 0));
     for (hipEvent_t ev : e->peerDone)                                        // a neighbour engine of this process may still be copying the last send face
         if (ev) HIP_TRY(hipStreamWaitEvent(e->xstream, ev, 0));
+    if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[1], e->xstream));
     if ((rc = slab_pack_on(e, e->xstream))) return rc;
     HIP_TRY(hipEventRecord(e->evPacked, e->xstream));
-    e->stepPending = true;
+    if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[2], e->xstream));
+    e->stepPending = true; e->stepPaused = false;
     return SPH_OK;
 }
 static int slab_step_join(SphEngine* e) {
+    if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[4], e->xstream));
     HIP_TRY(hipEventRecord(e->evDone, e->xstream));
     HIP_TRY(hipStreamWaitEvent(e->stream, e->evDone, 0));                    // the next substep's grid build sees the received records
     e->stepPending = false;
@@ -1332,21 +1444,30 @@ int sph_slab_step_finish_local(SphEngine* e, SphEngine* lo, SphEngine* hi) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     if (!e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_finish_local without sph_slab_step_begin");
     if ((e->hasLo != 0) != (lo != nullptr) || (e->hasHi != 0) != (hi != nullptr)) return fail(SPH_ERR_ARG, "neighbour engines do not match the slab's faces");
-    for (SphEngine* nb : {lo, hi})
-        if (nb && !nb->evPacked) return fail(SPH_ERR_STATE, "a neighbour engine has not begun its step");
-    const size_t bytes = ((size_t)e->faceCap + 1) * sizeof(SlabRec);
-    if (lo) {
-        if (lo->faceCap != e->faceCap) return fail(SPH_ERR_ARG, "face capacities differ");
-        HIP_TRY(hipStreamWaitEvent(e->xstream, lo->evPacked, 0));
-        HIP_TRY(hipMemcpyAsync(e->d_face[2], lo->d_face[1], bytes, hipMemcpyDeviceToDevice, e->xstream));    // its "send hi" is my "receive lo"
+    for (SphEngine* nb : {lo, hi}) {
+        if (!nb) continue;
+        if (!nb->evPacked || nb->stepNo != e->stepNo)       // (stepNo counts the begins: the neighbour's pack of THIS step is enqueued)
+            return fail(SPH_ERR_STATE, "a neighbour engine has not begun THIS step (call every engine's sph_slab_step_begin before any sph_slab_step_finish_local)");
+        if (nb->stepPaused != e->stepPaused) return fail(SPH_ERR_STATE, "param_pause differs between neighbouring slab engines");
+        if (nb->faceCap != e->faceCap) return fail(SPH_ERR_ARG, "face capacities differ");
     }
-    if (hi) {
-        if (hi->faceCap != e->faceCap) return fail(SPH_ERR_ARG, "face capacities differ");
-        HIP_TRY(hipStreamWaitEvent(e->xstream, hi->evPacked, 0));
-        HIP_TRY(hipMemcpyAsync(e->d_face[3], hi->d_face[0], bytes, hipMemcpyDeviceToDevice, e->xstream));
-    }
+    if (e->stepPaused) { e->stepPending = false; return SPH_OK; }   // (stepPaused keeps saying what this step was: the neighbours compare)
     int rc;
-    if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap))) return rc;
+    if ((rc = slab_size_messages(e))) return rc;
+    // the neighbour's send face -> this engine's receive face: header + migrants in use, halo copies in use (what sph_slab_step_finish
+    // sends with ncclSend / ncclRecv), behind the neighbour's pack
+    for (int d = 0; d < 2; ++d) {
+        SphEngine* nb = d ? hi : lo;
+        if (!nb) continue;
+        const char* src = nb->d_face[d ? 0 : 1];                             // its "send lo" is my "receive hi" and the other way round
+        char* dst = e->d_face[2 + d];
+        HIP_TRY(hipStreamWaitEvent(e->xstream, nb->evPacked, 0));
+        HIP_TRY(hipMemcpyAsync(dst, src, sizeof(SlabHdr) + (size_t)e->msgRecv[2 + d] * 64u, hipMemcpyDeviceToDevice, e->xstream));
+        HIP_TRY(hipMemcpyAsync(dst + slab_face_halo_off(e->faceCap), src + slab_face_halo_off(e->faceCap), (size_t)e->msgRecv[d] * 40u, hipMemcpyDeviceToDevice, e->xstream));
+    }
+    if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[3], e->xstream));
+    if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap, e->msgRecv))) return rc;
+    if ((rc = slab_note_counts(e, e->xstream))) return rc;
     if ((rc = slab_step_join(e))) return rc;
     if (lo) lo->peerDone[1] = e->evDone;                                     // their next pack overwrites the face this engine has just read
     if (hi) hi->peerDone[0] = e->evDone;
@@ -1356,11 +1477,47 @@ int sph_slab_status(SphEngine* e, uint32_t out[5]) {
     if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
     if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
     uint32_t host[8];
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->xstream) HIP_TRY(hipStreamSynchronize(e->xstream));
     HIP_TRY(hipMemcpyAsync(host, e->d_slabCnt, sizeof(host), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < 5; ++i) out[i] = host[i];
-    out[0] += host[5]; out[1] += host[6];                   // the async pack keeps its counts there (k_slab_headers resets [0], [1])
-    return slab_flags_error(e, host[4], out[0], out[1]);
+    out[0] += host[5]; out[1] += host[6];                   // the async pack keeps its counts there (the header kernels reset the running ones)
+    return slab_flags_error(e, host[4], out[0], out[1]);    // (flag 16 alone is a notice, not an error: out[4] carries it)
+}
+int sph_slab_clear_flags(SphEngine* e, uint32_t mask) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->xstream) HIP_TRY(hipStreamSynchronize(e->xstream));
+    uint32_t f = 0;
+    HIP_TRY(hipMemcpy(&f, e->d_slabCnt + 4, sizeof(f), hipMemcpyDeviceToHost));
+    f &= ~mask;
+    HIP_TRY(hipMemcpy(e->d_slabCnt + 4, &f, sizeof(f), hipMemcpyHostToDevice));
+    return SPH_OK;
+}
+int sph_slab_message_bytes(SphEngine* e, uint64_t out[4]) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab || !e->faceCap) return fail(SPH_ERR_STATE, "slab engine with face buffers required");
+    out[0] = e->sentBytes[0]; out[1] = e->sentBytes[1];
+    out[2] = e->hasLo ? (uint64_t)slab_face_bytes(e->faceCap) : 0u; out[3] = e->hasHi ? (uint64_t)slab_face_bytes(e->faceCap) : 0u;
+    return SPH_OK;
+}
+int sph_slab_step_times(SphEngine* e, float outMs[5]) {
+    if (!e || !outMs) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab || !e->xstream || !e->optTiming) return fail(SPH_ERR_STATE, "needs a slab engine that has run a boundary-first step with SPH_OPT_TIMING on");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->xstream));
+    // {pack, transfer, unpack} durations on the exchange stream, then when the exchange ended and when the SPH pass ended, both measured from the pass's start
+    float v[5] = {0, 0, 0, 0, 0};
+    hipError_t er = hipEventElapsedTime(&v[0], e->evX[1], e->evX[2]);
+    if (er == hipSuccess) er = hipEventElapsedTime(&v[1], e->evX[2], e->evX[3]);
+    if (er == hipSuccess) er = hipEventElapsedTime(&v[2], e->evX[3], e->evX[4]);
+    if (er == hipSuccess) er = hipEventElapsedTime(&v[3], e->evX[0], e->evX[4]);
+    if (er == hipSuccess && e->evPassEnd) er = hipEventElapsedTime(&v[4], e->evX[0], e->evPassEnd);
+    if (er != hipSuccess) return fail(SPH_ERR_STATE, "no timed boundary-first step yet: %s", hipGetErrorString(er));
+    for (int i = 0; i < 5; ++i) outMs[i] = v[i];
+    return SPH_OK;
 }
 
 }  // extern "C"
@@ -1454,7 +1611,9 @@ int sph_comm_destroy(SphComm* c) {
 // itself (RCCL serves a self send / recv with a device copy), issued the way slab_transfer_rccl issues the face messages
 // (ncclUint8 counts, a non-blocking stream that is not the null stream), then compared word for word on the host.
 // It is the only way to run ncclSend / ncclRecv on a box with one GPU (RCCL refuses two ranks on one device).
-int sph_comm_selftest(SphComm* c, uint64_t bytes) {
+int sph_comm_selftest(SphComm* c, uint64_t bytes) { return sph_comm_selftest_timed(c, bytes, nullptr); }
+// (msOut: hipEvent time of the grouped send + receive alone)
+int sph_comm_selftest_timed(SphComm* c, uint64_t bytes, float* msOut) {
     if (!c || !c->comm) return fail(SPH_ERR_ARG, "null communicator");
     if (bytes == 0 || bytes > (1ull << 30) || (bytes & 3ull)) return fail(SPH_ERR_ARG, "bytes must be a multiple of 4 in (0, 2^30]");
     const size_t words = (size_t)(bytes / 4);
@@ -1469,11 +1628,19 @@ int sph_comm_selftest(SphComm* c, uint64_t bytes) {
     if (er == hipSuccess) er = hipMemcpyAsync(src, host.data(), bytes, hipMemcpyHostToDevice, st);
     if (er == hipSuccess) er = hipMemsetAsync(dst, 0, bytes, st);
     if (er != hipSuccess) { cleanup(); return fail(SPH_ERR_HIP, "self-test setup failed: %s", hipGetErrorString(er)); }
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (msOut) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); (void)hipEventRecord(t0, st); }
     ncclResult_t g0 = g_rccl.GroupStart();
     ncclResult_t r = g0;
     if (r == ncclSuccess) r = g_rccl.Send(src, (size_t)bytes, ncclUint8, c->rank, c->comm, st);
     if (r == ncclSuccess) r = g_rccl.Recv(dst, (size_t)bytes, ncclUint8, c->rank, c->comm, st);
     ncclResult_t g1 = g0 == ncclSuccess ? g_rccl.GroupEnd() : g0;
+    if (msOut) {
+        *msOut = 0.0f;
+        (void)hipEventRecord(t1, st);
+        if (hipEventSynchronize(t1) == hipSuccess) (void)hipEventElapsedTime(msOut, t0, t1);
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    }
     if (r != ncclSuccess || g1 != ncclSuccess) {
         (void)hipStreamSynchronize(st);
         cleanup();
@@ -1520,19 +1687,20 @@ static int slab_check_comm(SphEngine* e, SphComm* c) {
     }
     return SPH_OK;
 }
-// the grouped ncclSend / ncclRecv with the (at most two) z-neighbours of fixed-size messages (header record + faceCap payload records)
+// the grouped ncclSend / ncclRecv with the (at most two) z-neighbours: per direction the header + the migrants in use, and the halo
+// copies in use (sizes: slab_size_messages; both ends of a link derive them from the same counts)
 static int slab_transfer_rccl(SphEngine* e, SphComm* c, hipStream_t st) {
-    const size_t bytes = ((size_t)e->faceCap + 1) * sizeof(SlabRec);
     if (e->hasLo || e->hasHi) {
+        const size_t hoff = slab_face_halo_off(e->faceCap);
         NCCL_TRY(g_rccl.GroupStart());
         ncclResult_t r = ncclSuccess;
-        if (e->hasLo) {
-            r = g_rccl.Send(e->d_face[0], bytes, ncclUint8, c->rank - 1, c->comm, st);
-            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2], bytes, ncclUint8, c->rank - 1, c->comm, st);
-        }
-        if (r == ncclSuccess && e->hasHi) {
-            r = g_rccl.Send(e->d_face[1], bytes, ncclUint8, c->rank + 1, c->comm, st);
-            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[3], bytes, ncclUint8, c->rank + 1, c->comm, st);
+        for (int d = 0; d < 2 && r == ncclSuccess; ++d) {
+            if (!(d ? e->hasHi : e->hasLo)) continue;
+            const int peer = d ? c->rank + 1 : c->rank - 1;
+            r = g_rccl.Send(e->d_face[d], sizeof(SlabHdr) + (size_t)e->msgSend[2 + d] * 64u, ncclUint8, peer, c->comm, st);
+            if (r == ncclSuccess) r = g_rccl.Send(e->d_face[d] + hoff, (size_t)e->msgSend[d] * 40u, ncclUint8, peer, c->comm, st);
+            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2 + d], sizeof(SlabHdr) + (size_t)e->msgRecv[2 + d] * 64u, ncclUint8, peer, c->comm, st);
+            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2 + d] + hoff, (size_t)e->msgRecv[d] * 40u, ncclUint8, peer, c->comm, st);
         }
         ncclResult_t g = g_rccl.GroupEnd();
         if (r != ncclSuccess) return fail(SPH_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
@@ -1541,15 +1709,18 @@ static int slab_transfer_rccl(SphEngine* e, SphComm* c, hipStream_t st) {
     return SPH_OK;
 }
 // One halo exchange of a substep: pack -> one grouped ncclSend / ncclRecv per z-neighbour -> unpack, all enqueued on the
-// engine's stream: no host synchronisation, and the stream order makes the unpack wait for the receives and the next pack
-// wait for the sends.
+// engine's stream: no host synchronisation on the path (the message sizes come from counts that are two exchanges old), and the
+// stream order makes the unpack wait for the receives and the next pack wait for the sends.
 int sph_slab_exchange(SphEngine* e, SphComm* c) {
     int rc;
     if ((rc = slab_check_comm(e, c))) return rc;
     if (e->stepPending) return fail(SPH_ERR_STATE, "a boundary-first step is pending: finish it with sph_slab_step_finish");
+    if (e->params.param_pause) return SPH_OK;                // the paused sph_dispatch that follows is a no-op: the halo records in place stay valid
+    if ((rc = slab_size_messages(e))) return rc;
     if ((rc = sph_slab_pack_async(e))) return rc;
     if ((rc = slab_transfer_rccl(e, c, e->stream))) return rc;
-    return sph_slab_unpack_async(e, e->d_face[2], e->d_face[3], e->faceCap);
+    if ((rc = slab_unpack_on(e, e->stream, e->d_face[2], e->d_face[3], e->faceCap, e->msgRecv))) return rc;
+    return slab_note_counts(e, e->stream);
 }
 // Second half of a boundary-first substep with RCCL as the transport: the transfer and the unpack follow the pack on the
 // exchange stream; the engine's stream (the interior of the SPH pass) only waits for them at its end.
@@ -1557,8 +1728,12 @@ int sph_slab_step_finish(SphEngine* e, SphComm* c) {
     int rc;
     if ((rc = slab_check_comm(e, c))) return rc;
     if (!e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_finish without sph_slab_step_begin");
+    if (e->stepPaused) { e->stepPending = false; return SPH_OK; }
+    if ((rc = slab_size_messages(e))) return rc;
     if ((rc = slab_transfer_rccl(e, c, e->xstream))) return rc;
-    if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap))) return rc;
+    if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[3], e->xstream));
+    if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap, e->msgRecv))) return rc;
+    if ((rc = slab_note_counts(e, e->xstream))) return rc;
     return slab_step_join(e);
 }
 

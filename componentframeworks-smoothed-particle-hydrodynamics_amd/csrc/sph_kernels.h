@@ -756,6 +756,38 @@ __device__ __forceinline__ void slab_append(SlabRec* buf, uint32_t* counter, uin
 //   owned, crossed into a neighbour  -> record sent as a migrant; kept here as a ghost if it sits in the
 //                                       adjacent layer, otherwise dead
 // counters[0] = records for the lower neighbour, counters[1] = for the upper neighbour.
+// COMPACT (round 4, the engine-owned face buffers): halo copies travel as 40-byte HaloRec (what a candidate needs: position, velocity,
+// density, pressure, id, flags), only migrants as full 64-byte records; sendLo / sendHi then point at a face buffer (SlabFace layout
+// below) and counters[8..11] count halo lo / hi, migrant lo / hi.
+struct HaloRec {
+    float px, py, pz, vx, vy, vz, rho, prs;
+    uint32_t id, flags;
+};
+static_assert(sizeof(HaloRec) == 40, "HaloRec is 40 bytes");
+struct SlabHdr {                                        // first 64 bytes of a face buffer / of the migrant message
+    uint32_t magic, nHalo, nHaloTrue, nMig, nMigTrue, exchange, pad[10];
+};
+static_assert(sizeof(SlabHdr) == 64, "SlabHdr is 64 bytes");
+// A face buffer of capacity cap: [SlabHdr][cap x SlabRec migrants][cap x HaloRec halo copies].  Two messages per direction and
+// exchange: header + the migrants in use, and the halo copies in use.
+__host__ __device__ __forceinline__ size_t slab_face_mig_off() { return sizeof(SlabHdr); }
+__host__ __device__ __forceinline__ size_t slab_face_halo_off(uint32_t cap) { return sizeof(SlabHdr) + (size_t)cap * 64u; }
+__host__ __device__ __forceinline__ size_t slab_face_bytes(uint32_t cap) { return sizeof(SlabHdr) + (size_t)cap * (64u + 40u); }
+
+template <class R>
+__device__ __forceinline__ void slab_append_t(R* buf, uint32_t* counter, uint32_t cap, bool pred, const R& r) {
+    const unsigned long long m = __ballot(pred);
+    if (!pred) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot < cap) buf[slot] = r;
+}
+
+template <bool COMPACT>
 __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, int hasLo, int hasHi, float4* __restrict__ pos,
                                                       const float4* __restrict__ vel, const float2* __restrict__ rp,
                                                       const float* __restrict__ foam, const float4* __restrict__ acc, int nBound, SlabRec* __restrict__ sendLo,
@@ -766,12 +798,12 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
     const int n = min(nBound, (int)counters[2]);       // counters[2] = slots that hold data (live count of the last sort)
     if ((int)(blockIdx.x * kBlock) >= n) return;       // whole block beyond the data
     // cellStart != nullptr: the slots are still in the order of the last counting sort (z-major) and nothing moved a
-    // particle by more than one cell layer since (unchanged container; a substep that did is reported, slab_check_layer_move).  Everything this pass acts on --
-    // stale ghosts, face particles, migrants -- then entered that substep in one of the three lowest or three highest
+    // particle by more than kSlabJump cell layers since (unchanged container; a substep that did is reported, slab_check_layer_move).  Everything this pass acts on --
+    // stale ghosts, face particles, migrants -- then entered that substep in one of the kSlabDepth lowest or highest
     // local layers, i.e. sits in two slot ranges at the ends; blocks in between have nothing to do.
     bool inEnds = true;
-    if (cellStart && gzLocal > 6) {
-        const int endLo = (int)cellStart[3 * layerCells], startHi = (int)cellStart[(gzLocal - 3) * layerCells];
+    if (cellStart && gzLocal > 2 * kSlabDepth) {
+        const int endLo = (int)cellStart[kSlabDepth * layerCells], startHi = (int)cellStart[(gzLocal - kSlabDepth) * layerCells];
         const int b0 = (int)(blockIdx.x * kBlock);
         if (b0 >= endLo && b0 + kBlock <= startHi) return;
         // exactly the two ranges, slot by slot: the boundary-first substep (sph_slab_step_begin) runs this pass while the SPH
@@ -806,10 +838,23 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(SimK k, int z0, int z1, in
             }
         }
     }
-    r.flags = fLo;
-    slab_append(sendLo, &counters[0], capLo, toLoBuf, r);
-    r.flags = fHi;
-    slab_append(sendHi, &counters[1], capHi, toHiBuf, r);
+    if (!COMPACT) {
+        r.flags = fLo;
+        slab_append(sendLo, &counters[0], capLo, toLoBuf, r);
+        r.flags = fHi;
+        slab_append(sendHi, &counters[1], capHi, toHiBuf, r);
+    } else {
+        HaloRec hr;
+        hr.px = r.px; hr.py = r.py; hr.pz = r.pz; hr.vx = r.vx; hr.vy = r.vy; hr.vz = r.vz; hr.rho = r.rho; hr.prs = r.prs; hr.id = r.id;
+        char* const fl = reinterpret_cast<char*>(sendLo);
+        char* const fh = reinterpret_cast<char*>(sendHi);
+        r.flags = fLo; hr.flags = fLo;
+        slab_append_t(reinterpret_cast<SlabRec*>(fl + slab_face_mig_off()), &counters[10], capLo, toLoBuf && !(fLo & F_HALO), r);
+        slab_append_t(reinterpret_cast<HaloRec*>(fl + slab_face_halo_off(capLo)), &counters[8], capLo, toLoBuf && (fLo & F_HALO), hr);
+        r.flags = fHi; hr.flags = fHi;
+        slab_append_t(reinterpret_cast<SlabRec*>(fh + slab_face_mig_off()), &counters[11], capHi, toHiBuf && !(fHi & F_HALO), r);
+        slab_append_t(reinterpret_cast<HaloRec*>(fh + slab_face_halo_off(capHi)), &counters[9], capHi, toHiBuf && (fHi & F_HALO), hr);
+    }
 }
 
 // What a received record tells about the exchange's one assumption -- no particle crosses more than one cell layer in z per
@@ -897,6 +942,79 @@ __global__ void k_slab_commit(uint32_t* __restrict__ counters, const SlabRec* __
         if (h.flags != kSlabMagic || h.id > recvCap) err |= 4u;
         else { add += h.id; if (h.pad > h.id) err |= 8u; }
     }
+    if (err) atomicOr(&counters[4], err);
+    counters[2] = min(counters[2] + add, slotCap);
+}
+
+// ---- round 4: the compact faces (SlabFace layout above).  counters: [8] halo copies for lo, [9] for hi, [10] migrants for lo, [11] for hi
+// (running, reset here), [12..15] the same four of the last pack (sph_slab_status / the host's message sizing), [7] exchanges so far.
+__global__ void k_slab_headers2(uint32_t* __restrict__ counters, char* __restrict__ faceLo, char* __restrict__ faceHi, uint32_t cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t ex = counters[7];
+    for (int d = 0; d < 2; ++d) {
+        char* f = d ? faceHi : faceLo;
+        const uint32_t nh = counters[8 + d], nm = counters[10 + d];
+        if (nh > cap || nm > cap) atomicOr(&counters[4], 1u);
+        if (f) {
+            SlabHdr h;
+            h.magic = kSlabMagic; h.nHalo = min(nh, cap); h.nHaloTrue = nh; h.nMig = min(nm, cap); h.nMigTrue = nm; h.exchange = ex;
+            for (int i = 0; i < 10; ++i) h.pad[i] = 0u;
+            *reinterpret_cast<SlabHdr*>(f) = h;
+        }
+        counters[12 + d] = nh; counters[14 + d] = nm;
+        counters[8 + d] = 0u; counters[10 + d] = 0u;
+    }
+    counters[5] = counters[12] + counters[14]; counters[6] = counters[13] + counters[15];   // what sph_slab_status reports: records per direction
+    counters[7] = ex + 1u;
+}
+// What of a received face may be used: the header must be one, and the counts are cut to what the MESSAGES carried
+// (msgHalo / msgMig records: the receiver sized them from the sender's counts of two exchanges ago; more than that -> error bit 8).
+struct FaceCounts { uint32_t nHalo, nMig; bool bad, more; };
+__device__ __forceinline__ FaceCounts slab_face_counts(const char* __restrict__ face, uint32_t cap, uint32_t msgHalo, uint32_t msgMig) {
+    FaceCounts c{0u, 0u, false, false};
+    if (!face) return c;
+    const SlabHdr h = *reinterpret_cast<const SlabHdr*>(face);
+    if (h.magic != kSlabMagic || h.nHalo > cap || h.nMig > cap) { c.bad = true; return c; }
+    c.nHalo = min(h.nHalo, msgHalo); c.nMig = min(h.nMig, msgMig);
+    c.more = h.nHaloTrue > c.nHalo || h.nMigTrue > c.nMig;
+    return c;
+}
+// Appends one received face behind slot counters[2] (+ `before` records of the face unpacked first): halo copies, then migrants.
+__global__ __launch_bounds__(kBlock) void k_slab_unpack2(const char* __restrict__ face, const char* __restrict__ otherFirst, uint32_t cap, uint32_t msgHalo, uint32_t msgMig,
+                                                         uint32_t otherMsgHalo, uint32_t otherMsgMig, float4* __restrict__ pos, float4* __restrict__ vel,
+                                                         float2* __restrict__ rp, float* __restrict__ foam, float4* __restrict__ acc, uint32_t* __restrict__ counters,
+                                                         uint32_t slotCap, SlabGeom g, int fromLo) {
+    const FaceCounts c = slab_face_counts(face, cap, msgHalo, msgMig);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.nHalo + c.nMig) return;
+    const FaceCounts o = slab_face_counts(otherFirst, cap, otherMsgHalo, otherMsgMig);
+    const uint32_t d = counters[2] + o.nHalo + o.nMig + i;
+    if (d >= slotCap) { atomicOr(&counters[4], 2u); return; }
+    if (i < c.nHalo) {
+        const HaloRec r = reinterpret_cast<const HaloRec*>(face + slab_face_halo_off(cap))[i];
+        pos[d] = make_float4(r.px, r.py, r.pz, bitsf(r.flags));
+        vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
+        rp[d] = make_float2(r.rho, r.prs);
+        foam[d] = 0.0f;
+        acc[d] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        const SlabRec r = reinterpret_cast<const SlabRec*>(face + slab_face_mig_off())[i - c.nHalo];
+        pos[d] = make_float4(r.px, r.py, r.pz, bitsf(r.flags));
+        vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
+        rp[d] = make_float2(r.rho, r.prs);
+        foam[d] = r.foam;
+        acc[d] = make_float4(r.ax, r.ay, r.az, 0.0f);
+        if (slab_record_misplaced(g, r, fromLo != 0)) atomicOr(&counters[4], 16u);
+    }
+}
+__global__ void k_slab_commit2(uint32_t* __restrict__ counters, const char* __restrict__ recvLo, const char* __restrict__ recvHi, uint32_t cap, uint32_t slotCap,
+                               uint32_t msgHaloLo, uint32_t msgMigLo, uint32_t msgHaloHi, uint32_t msgMigHi) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t add = 0u, err = 0u;
+    const FaceCounts a = slab_face_counts(recvLo, cap, msgHaloLo, msgMigLo), b = slab_face_counts(recvHi, cap, msgHaloHi, msgMigHi);
+    if (a.bad || b.bad) err |= 4u;
+    if (a.more || b.more) err |= 8u;
+    add = a.nHalo + a.nMig + b.nHalo + b.nMig;
     if (err) atomicOr(&counters[4], err);
     counters[2] = min(counters[2] + add, slotCap);
 }

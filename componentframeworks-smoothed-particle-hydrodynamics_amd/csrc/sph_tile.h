@@ -175,9 +175,12 @@ __global__ __launch_bounds__(NW * 64, SPH_TILE_OCC) void k_sph_tile(SimK k, Sort
                 qz = fmaf(0.995f * fmaf(k.gravz, k.dt, o.vz), k.dt, o.pz);
     const float mvx = qx - o.px, mvy = qy - o.py, mvz = qz - o.pz;
     const float ex = mvx + mvx, ey = mvy + mvy, ez = mvz + mvz;
-    const float c0 = dot3(mvx, mvy, mvz, mvx, mvy, mvz) - (hp * hp) * 1.0001f;
+    const float mm = dot3(mvx, mvy, mvz, mvx, mvy, mvz);
+    const float c0 = mm - (hp * hp) * 1.0001f;
     constexpr float kBig = 0x1p40f;
-    bool listOk = !(dbg & 1);
+    // (the rounding of w grows with |m|^2: beyond 16 h of predicted move -- an uploaded or impulse-driven velocity far above the cap --
+    //  the sign of s is no longer safe, and such a target takes the exact sweeps)
+    bool listOk = !(dbg & 1) && !(mm > 256.0f * k.h2);
     uint32_t cur = (uint32_t)tid * 2u;
     const uint32_t curEnd = (uint32_t)tid * 2u + (uint32_t)MAXN * kRowBytes;
     const uint32_t adv = live ? kRowBytes : 0u;

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     const float mvx = qx - o.px, mvy = qy - o.py, mvz = qz - o.pz;
     const float ex = mvx + mvx, ey = mvy + mvy, ez = mvz + mvz;
     // w = |d + m|^2 - hp^2 up to rounding (the slack left by the `near` test below is 1e3 times the rounding); hp^2 a little large
-    const float c0 = dot3(mvx, mvy, mvz, mvx, mvy, mvz) - (hp * hp) * 1.0001f;
+    const float mm = dot3(mvx, mvy, mvz, mvx, mvy, mvz);
+    const float c0 = mm - (hp * hp) * 1.0001f;
     constexpr float kBig = 0x1p40f;                        // (h2 - r2 > 0) * 2^40 outweighs any w of a 27-cell candidate
     uint32_t qs[9], qe[9];                                 // all 18 run bounds first (independent loads in flight)
 #pragma unroll
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
         qs[r] = in ? a : 0u; qe[r] = in ? b : 0u;
     }
-    bool listOk = !(dbg & 1);
+    // (the rounding of w grows with |m|^2: beyond 16 h of predicted move -- an uploaded or impulse-driven velocity far above the cap --
+    //  the sign of s is no longer safe, and such a target takes the exact sweeps)
+    bool listOk = !(dbg & 1) && !(mm > 256.0f * k.h2);
     // ---- sweep 1: density over every candidate (branch-free: a rejected candidate adds +0), and the list ----
     uint32_t cur = (uint32_t)tid * 2u;                     // byte offset of this thread's next list entry inside nl
     const uint32_t curEnd = (uint32_t)tid * 2u + (uint32_t)MAXN * kRowBytes;

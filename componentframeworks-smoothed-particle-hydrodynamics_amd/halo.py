@@ -35,6 +35,16 @@ OUT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("vel", "<f4", (3,)), ("acc", "<f4",
 assert OUT_DTYPE.itemsize == 64
 
 
+def _grid_key(p):
+    """The grid ComputeGridExtents makes of the members (SPHFluid3D.cpp:354-376): the halo records in place were cut for one grid."""
+    g = _eng.compute_grid_extents(p)
+    return (tuple(float(v) for v in g.gridMin), float(g.cellSize), tuple(int(v) for v in g.dims))
+
+
+def _paused(engine) -> bool:
+    return bool(getattr(getattr(engine, "_p", None), "param_pause", 0))
+
+
 def slab_range(gz: int, rank: int, world: int):
     """Even split of gz cell layers.  Every rank needs at least TWO layers: with a single layer a migrant that
     arrives from below would have to be forwarded upwards as a halo copy in the same substep (it is only known after
@@ -78,7 +88,6 @@ class HipSlabEngine:
     def alloc_faces(self, face_cap: int):
         _eng._check(self._L.sph_slab_alloc_faces(self._h, int(face_cap)))
         self.face_cap = int(face_cap)
-        self.face_cap = int(face_cap)
 
     def face_ptr(self, which: int) -> int:
         p = C.c_void_p()
@@ -110,9 +119,26 @@ class HipSlabEngine:
         _eng._check(self._L.sph_sync(self._h))
 
     def status(self):
+        """[records packed for lo, for hi, slots in use, -, flags]; raises for the flags that lost records (1, 2, 4, 8).  Flag 16 (a particle
+        crossed more cell layers in one substep than the exchange follows) is a notice: it comes back in [4]."""
         out = (C.c_uint32 * 5)()
         _eng._check(self._L.sph_slab_status(self._h, out))
         return [int(x) for x in out]
+
+    def clear_flags(self, mask: int = 16):
+        _eng._check(self._L.sph_slab_clear_flags(self._h, int(mask)))
+
+    def message_bytes(self):
+        """{sent to lo, sent to hi (last exchange), bytes of a whole face lo, hi}"""
+        out = (C.c_uint64 * 4)()
+        _eng._check(self._L.sph_slab_message_bytes(self._h, out))
+        return [int(x) for x in out]
+
+    def step_times(self):
+        """ms of the last boundary-first step (SPH_OPT_TIMING on): pack, transfer, unpack, end of the exchange, end of the SPH pass (the last two from the step's start)"""
+        out = (C.c_float * 5)()
+        _eng._check(self._L.sph_slab_step_times(self._h, out))
+        return [float(x) for x in out]
 
     def dispatch(self, dt=-1.0):
         _eng._check(self._L.sph_set_params(self._h, C.byref(self._p)))
@@ -166,6 +192,12 @@ class RcclComm:
     def selftest(self, nbytes: int = 1 << 20):
         """One grouped ncclSend + ncclRecv of `nbytes` from this rank to itself, checked on the host (sph_comm_selftest)."""
         _eng._check(self._L.sph_comm_selftest(self._h, int(nbytes)))
+
+    def selftest_gbs(self, nbytes: int = 1 << 24) -> float:
+        """GB/s of one grouped ncclSend + ncclRecv of `nbytes` from this rank to itself (hipEvents around the group; checked on the host)."""
+        ms = C.c_float()
+        _eng._check(self._L.sph_comm_selftest_timed(self._h, int(nbytes), C.byref(ms)))
+        return nbytes / max(ms.value, 1e-6) / 1e6
 
     def close(self):
         if self._h:
@@ -313,15 +345,23 @@ class SlabSimulation:
     def DispatchCompute(self, overrideDt: float = -1.0):
         if isinstance(self.exchange, RcclComm):          # the measured path: everything behind the C-ABI, no host round trip
             if self.overlap:
-                if not getattr(self, "_primed", False):  # the first substep's halos; every later exchange rides inside a step
-                    self.engine.exchange(self.exchange)
-                    self._primed = True
+                # the first substep's halos; every later exchange rides inside a step.  A member that moves the grid (box centre /
+                # half / angles, h, grid_cap) invalidates the halo records in place: prime again (sph_slab_step_begin would refuse)
+                key = _grid_key(self.engine._p)
+                if not getattr(self, "_primed", False) or key != getattr(self, "_grid_key", None):
+                    if not self.engine._p.param_pause:
+                        _eng._check(self.engine._L.sph_set_params(self.engine._h, C.byref(self.engine._p)))
+                        self.engine.exchange(self.exchange)
+                        self._primed = True
+                        self._grid_key = key
                 self.engine.step_begin(overrideDt)
                 self.engine.step_finish(self.exchange)
                 return
-            self.engine.exchange(self.exchange)
+            self.engine.exchange(self.exchange)          # (a no-op while param_pause is set, like the dispatch behind it)
             self.engine.dispatch(overrideDt)
             return
+        if _paused(self.engine):                         # a paused DispatchCompute is a no-op (SPHFluid3D.cpp:432): no exchange either, or every
+            return                                       # paused substep would append one more set of halo copies behind the live slots
         n_lo, n_hi = self.engine.pack(self.send_lo, self.send_hi)
         m_lo, m_hi = self.exchange.exchange(self.send_lo, n_lo, self.send_hi, n_hi, self.recv_lo, self.recv_hi)
         self.engine.unpack(self.recv_lo, m_lo, self.recv_hi, m_hi)
@@ -400,14 +440,21 @@ class SlabGroup:
 
     def DispatchCompute(self, overrideDt: float = -1.0):
         if getattr(self, "_overlap", False):
-            if not self._primed:
+            key = _grid_key(self.sims[0].engine._p)
+            paused = bool(self.sims[0].engine._p.param_pause)
+            if (not self._primed or key != getattr(self, "_grid_key", None)) and not paused:
+                for s in self.sims:               # (a grid that moved between two steps: the halo records in place were cut for the old one)
+                    _eng._check(s.engine._L.sph_set_params(s.engine._h, C.byref(s.engine._p)))
                 self._exchange_async()
                 self._primed = True
+                self._grid_key = key
             for s in self.sims:                   # every begin before any finish: a finish waits for the neighbours' packs
                 s.engine.step_begin(overrideDt)
             for r, s in enumerate(self.sims):
                 s.engine.step_finish_local(self.sims[r - 1].engine if r > 0 else None,
                                            self.sims[r + 1].engine if r < len(self.sims) - 1 else None)
+            return
+        if _paused(self.sims[0].engine):                  # (the overlap path above leaves the no-op to the engines: sph_slab_step_begin / _finish_local)
             return
         if getattr(self, "_async_cap", 0):
             for s in self.sims:

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 2   /* 2: sph_slab_step_*, header validation of received halo messages, SPH_OPT_NEIGHBOR_KERNEL 3 (default), records on demand by default */
+#define SPH_ABI_VERSION 3   /* 3: compact halo faces (40-byte halo copies, count-sized messages), jumps of up to 3 cell layers followed, sph_slab_clear_flags / _message_bytes / _step_times / _face_bytes, flag 16 no longer an error, SPH_OPT_NEIGHBOR_KERNEL 4 */
+/* (2: sph_slab_step_*, header validation of received halo messages, SPH_OPT_NEIGHBOR_KERNEL 3 (default), records on demand by default) */
 
 enum {
     SPH_OK = 0,
@@ -122,7 +123,7 @@ typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHF
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
 enum {
-    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 3 = k_sph_walk (default: one target per lane, LDS-staged candidate rows, neighbour lists walked per lane over 32-byte records), 2 = k_sph_list (round 2's form of the same plan), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 4 = k_sph_tile (round 4, A/B: one workgroup per block of 8 x 4 x 4 cells, the block's hull staged once into LDS, all three sweeps out of LDS; blocks that do not fit go to k_sph_walk; single-domain engines only, a z-slab engine runs k_sph_walk), 3 = k_sph_walk (default: one target per lane, LDS-staged candidate rows, neighbour lists walked per lane over 32-byte records), 2 = k_sph_list (round 2's form of the same plan), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 1 = lazy (default): the substep keeps its state in the engine's own arrays and the 80-byte records are brought up to date by sph_device_particles() / sph_download_particles() / sph_pack_render_buffer(), i.e. once per rendered frame instead of once per substep (the scattered 52-byte update of every record costs about 13 % of the SPH pass); 0 = eager: the SPH pass also updates the records, they are current after every dispatch. Same values either way. */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
@@ -277,31 +278,48 @@ int sph_slab_unpack(SphEngine* e, const void* recvLo, uint32_t nLo, const void* 
 int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nOut);
 
 /* ---- the same exchange without host round trips, and its RCCL transport ------------------------------------------
- * The engine owns four device buffers of (faceCap + 1) records (send lo / hi, receive lo / hi); record 0 is a header whose
- * `id` word carries the record count, so counts never travel through the host.  Per substep a rank calls
- * sph_slab_exchange (pack -> one grouped ncclSend/ncclRecv per z-neighbour over xGMI -> unpack, all on the engine's
- * stream) and then sph_dispatch.  sph_slab_pack_async / sph_slab_unpack_async are the two halves for hosts that move the
- * buffers themselves (several slab engines in one process, another transport).  Overflows (send buffer, slot capacity)
- * set a device-side flag that sph_slab_status / sph_slab_download report.  faceCap is also the SIZE OF EVERY MESSAGE and
- * must be the same on all ranks of a communicator: the first sph_slab_exchange of an engine on a communicator checks
- * that with one ncclAllReduce (and one stream synchronisation) and fails instead of hanging.  A `stream` of NULL at
- * creation means an engine-owned stream: everything above is ordered on THAT stream. */
+ * The engine owns four device buffers (send lo / hi, receive lo / hi) of sph_slab_face_bytes(): a 64-byte header (magic, halo
+ * copies, migrants, the sender's true counts, exchange number), then faceCap 64-byte records for MIGRANTS (the layout above),
+ * then faceCap 40-byte records for HALO COPIES (float px,py,pz,vx,vy,vz,rho,prs; uint32 id, flags: what a neighbour candidate
+ * needs -- round 4).  Counts never travel through the host.  Per substep a rank calls sph_slab_exchange
+ * (pack -> per z-neighbour two grouped ncclSend / ncclRecv pairs over xGMI: header + migrants in use, halo copies in use ->
+ * unpack, all on the engine's stream) and then sph_dispatch.  MESSAGE SIZES: the records in use two exchanges ago + a quarter
+ * + 1024 (read back asynchronously into pinned memory, so the path never waits for the device; both ends of a link derive the
+ * size from the same number: the sender from its own count, the receiver from the header it received then), the whole face for
+ * the first two exchanges.  A message that turns out too small sets error flag 8 on the receiver (records were cut off).
+ * sph_slab_pack_async / sph_slab_unpack_async are the two halves for hosts that move the faces themselves (several slab
+ * engines in one process, another transport): move sph_slab_face_bytes() bytes, or the three parts in use.  Overflows (send
+ * face, slot capacity) set a device-side flag that sph_slab_status / sph_slab_download report.  faceCap must be the same on
+ * all ranks of a communicator: the first sph_slab_exchange of an engine on a communicator checks that with one ncclAllReduce
+ * (and one stream synchronisation) and fails instead of hanging.  A `stream` of NULL at creation means an engine-owned stream:
+ * everything above is ordered on THAT stream.  While param_pause is set sph_slab_exchange and the step calls below do nothing
+ * (as the paused DispatchCompute, SPHFluid3D.cpp:432): the halo records in place stay valid; all ranks must pause together. */
 #define SPH_COMM_ID_BYTES 128
+#define SPH_SLAB_HALO_BYTES 40
 typedef struct SphComm SphComm;
 int sph_slab_alloc_faces(SphEngine* e, uint32_t faceCap);
 int sph_slab_face_buffer(SphEngine* e, int which /* 0 send lo, 1 send hi, 2 recv lo, 3 recv hi */, void** devPtr);
+int sph_slab_face_bytes(SphEngine* e, uint64_t* bytes);
 int sph_slab_pack_async(SphEngine* e);
 int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap);
-/* Synchronises; out = {records packed for lo, for hi, slots in use, -, error flags}.  Error flags (device side, sticky; any of
- * them also makes this call and sph_slab_download return an error): 1 a send face overflowed, 2 the slot capacity overflowed
- * while appending received records, 4 a received message did not start with a valid header, 8 the neighbour had more records
- * than its message could carry, 16 a received particle had crossed MORE THAN ONE cell layer in z within one substep (it was
- * placed far outside the container, or the container moved by cells under the fluid): the exchange hands particles to the
- * adjacent rank only and halo copies exist one layer deep, so from then on the decomposed run no longer equals the
- * single-domain run.  (SPHFluid.comp moves a particle with the uncapped velocity (v + a dt) dt, so this is a property of the scene, not a guarantee:
- * the BASELINE workloads keep it through their whole collapse; the pack after a container change scans
+/* Synchronises; out = {records packed for lo, for hi, slots in use, -, flags}.  Flags (device side, sticky until
+ * sph_slab_clear_flags).  ERRORS -- records were lost; this call and sph_slab_download then return an error: 1 a send face
+ * overflowed, 2 the slot capacity overflowed while appending received records, 4 a received message did not start with a valid
+ * header, 8 the neighbour had more records than its message carried.  NOTICE -- nothing lost, the call succeeds and out[4]
+ * carries the bit: 16 a particle crossed MORE cell layers in z within one substep than the exchange follows.  The exchange
+ * follows up to 3 layers per substep (the pack and the face launches of a boundary-first step cover the 5 lowest / highest
+ * local layers; migrants go to the adjacent rank, which such a jump still reaches while every slab is at least 4 layers
+ * thick); beyond that -- a particle placed far outside the container, a container that moved by cells under the fluid, a
+ * slab thinner than the jump -- the decomposed run goes on but no longer equals the single-domain run, and says so here.
+ * (SPHFluid.comp moves a particle with the uncapped velocity (v + a dt) dt, so this is a property of the scene, not a guarantee:
+ * the BASELINE workloads stay far inside it through their whole collapse; the pack after a container change scans
  * every slot, so a change of shape alone is followed exactly as long as no particle has to cross a whole slab.) */
 int sph_slab_status(SphEngine* e, uint32_t out[5]);
+/* Clears the given flag bits (synchronises): a host acknowledges notice 16 and goes on. */
+int sph_slab_clear_flags(SphEngine* e, uint32_t mask);
+/* Bytes of the last exchange's messages to the lower / upper neighbour, and the bytes a whole face would be: {sent lo, sent hi,
+ * face lo, face hi} (host-side bookkeeping, no synchronisation). */
+int sph_slab_message_bytes(SphEngine* e, uint64_t out[4]);
 /* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy: rank 0 creates the id and hands its 128 bytes to the other ranks
  * by any means (MPI, a file, torch.distributed); one rank per process, on the current HIP device. */
 int sph_comm_unique_id(void* out128);
@@ -311,11 +329,13 @@ int sph_comm_destroy(SphComm* comm);
  * most 2^30) from the rank to itself on a non-blocking stream, compared on the host.  Synchronises.  (The only way to
  * execute ncclSend / ncclRecv on a one-GPU box: RCCL refuses two ranks on one device.) */
 int sph_comm_selftest(SphComm* comm, uint64_t bytes);
+/* The same, also returning the hipEvent time of the grouped send + receive alone (ms). */
+int sph_comm_selftest_timed(SphComm* comm, uint64_t bytes, float* msOut);
 int sph_slab_exchange(SphEngine* e, SphComm* comm);
 /* ---- boundary-first substep: the exchange hidden behind the interior of the SPH pass -----------------------------
  * sph_slab_step_begin = sph_dispatch, except that the SPH pass runs the slot ranges next to the slab's faces first (the
- * three lowest / three highest local cell layers: everything the next pack can touch as long as a substep moves a particle
- * across at most one layer; a substep that does not is reported, error flag 16 above), and then, on a second stream of the engine, the pack of the exchange that prepares the
+ * five lowest / five highest local cell layers: everything the next pack can touch as long as a substep moves a particle
+ * across at most three layers; a substep that does not is reported, flag 16 above), and then, on a second stream of the engine, the pack of the exchange that prepares the
  * NEXT substep -- while the interior slots are still being computed on the engine's stream.  The second half moves the
  * faces and unpacks, still on the second stream; the engine's stream waits for it only at its end:
  *   sph_slab_step_finish(engine, comm)            one process per GPU: grouped ncclSend / ncclRecv (RCCL over xGMI)
@@ -324,10 +344,17 @@ int sph_slab_exchange(SphEngine* e, SphComm* comm);
  * Both transports run the same stream / event schedule.  The state a step leaves behind already holds the halo records of
  * the next substep, so a run is: one plain exchange (sph_slab_exchange, or pack_async / unpack_async) to prime it, then
  * only steps; impulses go between steps as usual (they act on the halo copies as on their owners).  Members that move the
- * grid must not change between two steps.  Results are bit-identical to exchange + sph_dispatch. */
+ * grid (box centre / half / angles, h, grid_cap) must not change between two steps: sph_slab_step_begin compares the grid with the
+ * one the halo records in place were cut for and returns SPH_ERR_STATE (prime again with a plain exchange, then go on).  Every
+ * engine of a group must begin a step before any of them finishes it (sph_slab_step_finish_local checks the neighbours' step
+ * numbers).  Results are bit-identical to exchange + sph_dispatch. */
 int sph_slab_step_begin(SphEngine* e, float overrideDt);
 int sph_slab_step_finish(SphEngine* e, SphComm* comm);
 int sph_slab_step_finish_local(SphEngine* e, SphEngine* lo, SphEngine* hi);
+/* With SPH_OPT_TIMING on: hipEvent times of the LAST boundary-first step, in ms (synchronises): {pack, transfer, unpack} on the
+ * exchange stream, then the end of the exchange and the end of the SPH pass (interior included), both measured from the start of
+ * the step.  The transfer was hidden behind the interior iff out[3] <= out[4]. */
+int sph_slab_step_times(SphEngine* e, float outMs[5]);
 
 /* ---- measurement ----------------------------------------------------------------- */
 enum {

@@ -22,7 +22,7 @@ def test_exports_match_header(pkg):
     assert sorted(pkg.ABI_SYMBOLS) == declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sph_abi_version() == 2
+    assert L.sph_abi_version() == 3
 
 
 def test_struct_layouts(pkg):

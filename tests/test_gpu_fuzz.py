@@ -133,13 +133,13 @@ def test_random_scene_as_z_slabs_with_boundary_first_steps(pkg, oracle, seed):
         grp.DispatchCompute()
     reported = []
     for s in grp.sims:
-        try:
-            assert s.engine.status()[4] == 0
-        except pkg.SphError as ex:
-            assert "more than one cell layer" in str(ex), ex
-            reported.append(str(ex))
-    if reported:                                   # allowed only where a particle did cross more than one layer in some substep
-        assert worst_jump > 1, f"seed {seed}: largest layer jump {worst_jump}, yet: {reported[0]}: {what}"
+        st = s.engine.status()                     # (raises for the flags that lose records)
+        assert st[4] & ~16 == 0, st
+        if st[4] & 16:
+            reported.append(st)
+    if reported:                                   # allowed only where a particle crossed more layers than the exchange follows (3, or the slab's thickness)
+        thin = min(s.z1 - s.z0 for s in grp.sims)
+        assert worst_jump > 3 or (worst_jump > 1 and world > 2 and thin <= worst_jump), f"seed {seed}: largest layer jump {worst_jump} (thinnest slab {thin}), yet flag 16: {what}"
         for s in grp.sims:
             s.engine.close()
         return
@@ -287,8 +287,22 @@ def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
     want, worst, log = rec.copy(), 0, []
     moving = rec["isGhost"] != 1
     for _ in range(int(rng.integers(10, 18))):
-        opn = rng.choice(["dispatch", "dispatch", "dispatch", "wave", "param", "shape"])
-        if opn == "dispatch":
+        opn = rng.choice(["dispatch", "dispatch", "dispatch", "wave", "param", "shape", "pause", "move"])
+        if opn == "pause":                                   # a few paused DispatchCompute calls: no-ops, exchange included (SPHFluid3D.cpp:432)
+            sp.param_pause = 1
+            for _ in range(int(rng.integers(1, 4))):
+                grp.DispatchCompute()
+            sp.param_pause = 0
+        elif opn == "move":                                  # the container (and with it the grid) moves by about a cell between two steps
+            old_c = tuple(sp.param_boxCenter)
+            sp.param_boxCenter[2] = old_c[2] + float(rng.choice([-1.0, 1.0])) * float(sp.param_h)
+            if tuple(int(v) for v in pkg.compute_grid_extents(sp).dims) != dims:
+                sp.param_boxCenter[2] = old_c[2]
+                continue
+            op = to_oracle_params(oracle, sp)
+            g = pkg.compute_grid_extents(sp)
+            gm, cs = np.float32(g.gridMin[2]), np.float32(g.cellSize)
+        elif opn == "dispatch":
             dt = float(rng.choice([-1.0, -1.0, 5e-4]))
             grp.DispatchCompute(dt)
             nxt = oracle.substep(want, op, dt=dt)
@@ -315,13 +329,13 @@ def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
         log.append(opn)
     reported = []
     for s in grp.sims:
-        try:
-            assert s.engine.status()[4] == 0
-        except pkg.SphError as ex:
-            assert "more than one cell layer" in str(ex), ex
-            reported.append(str(ex))
+        st = s.engine.status()
+        assert st[4] & ~16 == 0, st
+        if st[4] & 16:
+            reported.append(st)
     if reported:
-        assert worst > 1, f"seed {seed}: largest layer jump {worst}, yet: {reported[0]}: {what}: {log}"
+        thin = min(s.z1 - s.z0 for s in grp.sims)
+        assert worst > 3 or (worst > 1 and world > 2 and thin <= worst), f"seed {seed}: largest layer jump {worst} (thinnest slab {thin}), yet flag 16: {what}: {log}"
     else:
         got = halo.merge_into_records(rec, grp.download())
         assert_records_equal(got, want, f"seed {seed} as {world} slabs: {what}: {log}")

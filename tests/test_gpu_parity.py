@@ -527,3 +527,22 @@ def test_pack_render_buffer_known_answer(pkg):
         got = out.cpu().numpy()
         assert np.array_equal(got[:, :3], rec["pos"][:, :3]) and np.array_equal(got[:, 3], np.float32(w)), (mode, got)
     f.close()
+
+
+@pytest.mark.parametrize("name,neighbor", NEIGHBOR_VARIANTS)
+def test_uploaded_velocities_far_above_the_cap(pkg, oracle, name, neighbor):
+    """Entry velocities are not bounded by maxSpeed (uploads, impulses): a predicted move of 100 h and of 500 h per substep must not
+    make the list test of k_sph_walk / k_sph_tile miss a neighbour (such targets take the exact sweeps)."""
+    rec, sp = small_scene(pkg, n=4096, grid=16, seed=35)
+    op = to_oracle_params(oracle, sp)
+    P = oracle.substep(rec, op, steps=2)
+    h, dt = float(sp.param_h), float(sp.param_timeStep)
+    rng = np.random.default_rng(11)
+    idx = rng.choice(len(P), 24, replace=False)
+    for j, i in enumerate(idx):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        P["vel"][i, :3] = (d * (100.0 if j % 2 == 0 else 500.0) * h / dt).astype(np.float32)
+    f = make_engine(pkg, P, sp, neighbor)
+    f.DispatchN(2)
+    assert_records_equal(f.download(), oracle.substep(P, op, steps=2), f"{name}: velocities of 100 h and 500 h per substep")
+    f.close()

@@ -145,3 +145,38 @@ def test_settled_pool_100_substeps_within_1e4_of_the_literal_arithmetic(pkg, ora
     (_, d25, p25, x25), (_, d100, p100, x100) = rows
     assert d25 <= 1e-4 and p25 <= 1e-4
     assert d100 <= 1e-4 and p100 <= 3e-4 and x100 <= 2e-5
+
+
+def test_config2_counting_sort_and_linked_list_against_the_oracle(pkg, oracle):
+    """BASELINE.json configs[1] at its own size (262 144 particles, 64^3 cells): the A/B of the two grid builds.  Counting sort
+    (this engine's build, every SPH pass) against the oracle bit for bit; the linked-list build (BuildGrid.comp:21-37 as it stands:
+    atomic arrival order, so sums are not reproducible) against the oracle within the tolerances of
+    tests/test_gpu_parity.py::test_linked_list_variant_within_tolerance."""
+    syn = pkg.synthetic
+    cfg = syn.CONFIGS[2]
+    rec, _ = syn.make_particles(cfg)
+    assert len(rec) == 262144
+    sp = pkg.default_params(**syn.params_fields(cfg))
+    assert tuple(pkg.compute_grid_extents(sp).dims) == (64, 64, 64)
+    op = to_oracle_params(oracle, sp)
+    want1 = oracle.substep(rec, op)
+    want3 = oracle.substep(want1, op, steps=2)
+    for name, neighbor in KERNELS + [("slow", 1)]:
+        f = _engine(pkg, rec, sp, neighbor)
+        f.DispatchN(3)
+        assert_records_equal(f.download(), want3, f"configs[1], counting sort + {name}, 3 substeps")
+        f.close()
+    f = _engine(pkg, want1, sp, 3)                           # (from a state with densities: the first substep after a reset has no pair terms)
+    f.set_option(pkg.SPH_OPT_GRID_BUILD, 1)
+    f.DispatchCompute()
+    got, want = f.download(), oracle.substep(want1, op)
+    err = _rel(want["density"], got["density"])
+    assert err.max() < 1e-5, err.max()
+    assert np.abs(got["pressure"] - want["pressure"]).max() <= sp.param_gasConstant * 1e-5 * want["density"].max()
+    assert np.abs(got["pos"] - want["pos"]).max() < 1e-5 and np.abs(got["vel"] - want["vel"]).max() < 1e-2
+    f.DispatchN(9)
+    got, want = f.download(), oracle.substep(want, op, steps=9)
+    err = _rel(want["density"], got["density"])
+    print("configs[1], linked list, 10 substeps: max rel density err", err.max())
+    assert err.max() < 1e-3
+    f.close()

@@ -384,3 +384,123 @@ def test_bench_slab_path_with_rccl_and_one_rank():
     st = d["slab_status"]
     assert st["overflow_on_any_rank"] is False and st["multi_layer_move_on_any_rank"] is False
     assert st["records_lo_hi_live_per_rank"][0][:2] == [0, 0] and st["records_lo_hi_live_per_rank"][0][2] == 8388608
+
+
+# ---- round 4: the exchange's protocol ----------------------------------------------------
+def test_paused_steps_leave_the_halo_records_alone(pkg, oracle):
+    """A paused DispatchCompute is a no-op (SPHFluid3D.cpp:432) and so is its exchange: 40 paused boundary-first steps on a 2-slab group
+    neither fill the slots with stale halo copies nor change a bit; after the pause the run goes on bit for bit."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, 2)
+    grp.enable_overlap(8192)
+    want = P
+    for _ in range(3):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+    slots_before = [s.engine.status()[2] for s in grp.sims]
+    sp.param_pause = 1
+    for _ in range(40):
+        grp.DispatchCompute()
+    assert [s.engine.status()[2] for s in grp.sims] == slots_before      # nothing was appended
+    sp.param_pause = 0
+    for _ in range(3):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+    st = [s.engine.status() for s in grp.sims]
+    assert all(x[4] == 0 for x in st), st
+    assert_records_equal(halo.merge_into_records(P, grp.download()), want, "2 slabs across 40 paused steps")
+
+
+def test_step_finish_before_the_neighbour_has_begun_is_refused(pkg, oracle):
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, 2)
+    grp.enable_overlap(8192)
+    grp.DispatchCompute()                                        # primes and runs one step on both
+    a, b = grp.sims[0].engine, grp.sims[1].engine
+    a.step_begin()
+    with pytest.raises(pkg.SphError, match="has not begun THIS step"):
+        a.step_finish_local(None, b)                             # b still holds the events of the step before
+    b.step_begin()
+    a.step_finish_local(None, b); b.step_finish_local(a, None)
+    want = oracle.substep(P, op, steps=2)
+    assert_records_equal(halo.merge_into_records(P, grp.download()), want, "2 slabs after a refused finish")
+
+
+def test_grid_change_between_two_steps_is_refused_by_the_abi_and_followed_by_the_driver(pkg, oracle):
+    """The halo records in place were cut for one grid: sph_slab_step_begin refuses a grid that moved since; the Python
+    driver primes again and stays bit-exact."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    grp = _group(pkg, halo, P, sp, 2)
+    grp.enable_overlap(8192)
+    want = P
+    for _ in range(2):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+    sp.param_boxCenter[2] = float(sp.param_boxCenter[2]) + float(sp.param_h)       # the grid moves by one cell in z
+    assert tuple(pkg.compute_grid_extents(sp).dims) == grp.sims[0].grid_dims
+    with pytest.raises(pkg.SphError, match="grid changed"):
+        grp.sims[0].engine.step_begin()
+    op = to_oracle_params(oracle, sp)
+    for _ in range(3):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+    st = [s.engine.status() for s in grp.sims]
+    assert all(x[4] & ~16 == 0 for x in st), st
+    if all(x[4] == 0 for x in st):                               # (the move itself may carry particles across more layers than the exchange follows)
+        assert_records_equal(halo.merge_into_records(P, grp.download()), want, "2 slabs across a grid that moved by a cell")
+
+
+def test_messages_shrink_to_the_records_in_use_and_halo_copies_are_40_bytes(pkg, oracle):
+    """After two exchanges the messages carry the records in use (+ 25 % + 1024) instead of whole faces, halo copies as 40-byte
+    records; same bits."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle, n=15000, grid=24)
+    grp = _group(pkg, halo, P, sp, 3)
+    cap = 20000
+    grp.enable_overlap(cap)
+    want = P
+    for _ in range(6):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+    assert_records_equal(halo.merge_into_records(P, grp.download()), want, "3 slabs, count-sized messages")
+    mid = grp.sims[1].engine
+    sent_lo, sent_hi, face_lo, face_hi = mid.message_bytes()
+    st = mid.status()
+    assert st[4] == 0 and face_lo == face_hi == 64 + cap * (64 + 40)
+    for sent, recs in ((sent_lo, st[0]), (sent_hi, st[1])):
+        assert 64 + recs * 40 <= sent <= 64 + (recs * 1.3 + 2 * 1024 + 64) * 64 and sent < face_lo / 4, (sent, recs, face_lo)
+
+
+def test_a_jump_across_a_whole_slab_is_a_notice_not_an_error(pkg, oracle):
+    """Flag 16 (a particle crossed more layers than the exchange follows) loses no record: sph_slab_download delivers, the status call
+    succeeds and carries the bit, sph_slab_clear_flags acknowledges it."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle)
+    cz, dims = _cell_z(pkg, sp, P)
+    g = pkg.compute_grid_extents(sp)
+    i = int(np.flatnonzero(cz == dims[2] // 3 - 1)[0])           # a particle in the top layer of the lowest of 3 slabs ...
+    P = P.copy()
+    P["vel"][i] = (0.0, 0.0, (dims[2] // 3 + 2) * float(g.cellSize) / float(sp.param_timeStep), 0.0)   # ... thrown across the whole middle slab
+    grp = _group(pkg, halo, P, sp, 3)
+    grp.enable_overlap(8192)
+    for _ in range(3):
+        grp.DispatchCompute()
+    st = [s.engine.status() for s in grp.sims]                   # does not raise
+    assert any(x[4] & 16 for x in st) and all(x[4] & ~16 == 0 for x in st), st
+    owned = grp.download()                                       # does not raise, nobody is lost
+    assert sorted(owned["id"].tolist()) == list(range(len(P)))
+    for s in grp.sims:
+        s.engine.clear_flags(16)
+    assert all(s.engine.status()[4] == 0 for s in grp.sims)
+
+
+def test_step_times_say_whether_the_exchange_was_hidden(pkg, oracle):
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle, n=15000, grid=24)
+    grp = _group(pkg, halo, P, sp, 2)
+    grp.enable_overlap(20000)
+    for s in grp.sims:
+        s.engine.set_option(pkg.SPH_OPT_TIMING, 1)
+    for _ in range(4):
+        grp.DispatchCompute()
+    for s in grp.sims:
+        pack, transfer, unpack, exchange_end, pass_end = s.engine.step_times()
+        assert pack > 0 and transfer >= 0 and unpack > 0 and exchange_end > 0 and pass_end > 0
