@@ -449,7 +449,17 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             hipLaunchKernelGGL(k_sph_ll, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, cellHead, e->d_llNext, n);
         }
     } else {
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3        // timing experiment only: substeps that reuse the kept lists also skip the grid build (frozen order)
+    if (!(e->debugFlags & 32))
+#endif
     if ((rc = build_grid(e, k, true))) return rc;                           // :449-468
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
+    static uint16_t* expLists = nullptr;
+    if (!expLists) { const size_t per = (size_t)SPH_WALK_MAXN * 256 + 2 * 256 + 2 * 4 * 16; if ((rc = dev_alloc(&expLists, per * (size_t)(8 * ((blocks_for(n, 256) + 7) / 8))))) return rc; }
+#define EXP_LISTS_ARG , expLists
+#else
+#define EXP_LISTS_ARG
+#endif
     if (n) {                                                                // :470-509 (SPH + OBB fused)
         if (!e->d_sPV || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
         const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
@@ -477,10 +487,10 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             auto walk = [&](hipStream_t st, const uint32_t* lo, const uint32_t* hi) {
                 if (k.h2 <= 1.0f)
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg);
+                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
                 else
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg);
+                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
             };
             // The pack of the next exchange only reads the slots of the kSlabDepth lowest / highest local cell layers (k_slab_pack,
             // under the same conditions): those two slot ranges first, the event, then everything in between.

@@ -101,7 +101,11 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
                                                                   const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n,
                                                                   int dbg, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ rangeLo,
                                                                   const uint32_t* __restrict__ rangeHi, const uint8_t* __restrict__ tileDone,
-                                                                  const uint32_t* __restrict__ nFallback, TileGeom tg) {
+                                                                  const uint32_t* __restrict__ nFallback, TileGeom tg
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3        // timing experiment only (tools/list_reuse_bound.py): the lists of one substep kept in global memory
+                                                                  , uint16_t* __restrict__ expLists
+#endif
+                                                                  ) {
     constexpr int kB = 256;
     constexpr uint32_t kRowBytes = kB * 2;                 // one list row = one entry of every thread
     static_assert(kRowBytes == 512, "the cursor advance reads bit 9 of (sign >> 22)");
@@ -205,10 +209,18 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
             if (CAP > 128) pre2 = S.P(A + min((uint32_t)lane + 128u, B - A - 1u));
         }
     };
-    plan(qs[0], qe[0]);
     int nRows = 0, nUnstaged = 0;
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
+    uint16_t* const expBase = expLists + (size_t)vb * (size_t)(MAXN * kB + 2 * kB + 2 * (kB / 64) * 16);
+    const bool expReuse = (dbg & 32) != 0;
+    if (!expReuse) plan(qs[0], qe[0]);
+#pragma unroll
+    for (int r = 0; r < (expReuse ? 0 : 9); ++r) {
+#else
+    plan(qs[0], qe[0]);
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
+#endif
         const uint32_t q0 = qs[r], q1 = qe[r];
         const bool ne = q1 > q0;
         const unsigned long long mne = mneN;
@@ -267,6 +279,26 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         }
     }
     __builtin_amdgcn_wave_barrier();                       // rowA written by lane 0, read by every lane below
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
+    {
+        uint32_t* const gCur = reinterpret_cast<uint32_t*>(expBase + MAXN * kB);
+        uint32_t* const gRowA = gCur + kB;
+        if (dbg & 64) {                                    // keep this substep's lists
+            for (int e = 0; e < MAXN; ++e) expBase[e * kB + tid] = nl[e][tid];
+            gCur[tid] = cur;
+            if (lane < 16) gRowA[wv * 16 + lane] = rowA[wv][lane];
+        }
+        if (expReuse) {                                    // sweep 1 = the kept lists (coalesced reads), then a walk for the density
+            cur = live ? gCur[tid] : (uint32_t)tid * 2u;
+            if (lane < 16) rowA[wv][lane] = gRowA[wv * 16 + lane];
+            const uint32_t rows = (cur - (uint32_t)tid * 2u) / kRowBytes;
+            uint32_t maxRows = rows;
+            for (int d = 32; d >= 1; d >>= 1) maxRows = max(maxRows, (uint32_t)__shfl_xor((int)maxRows, d, 64));
+            for (uint32_t e = 0; e < maxRows; ++e) nl[e][tid] = expBase[e * kB + tid];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#endif
     listOk = (listOk && cur < curEnd) || !live;            // a cursor that reached the end may have dropped entries; lanes without a target never fall back
     finish_density(k, o);
 
@@ -403,6 +435,19 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
 #if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 1   // timing experiment only: stop after sweep 1
     if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cur, o.ay, o.az, o.rho, o.prs, W_O.y, W_CZ);
     return;
+#endif
+#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
+    if (expReuse) {                                        // the density from the kept list (one 16-byte gather per entry) + the target itself
+        auto density_at = [&](const float4& J, const float4&) {
+            const float dx = o.px - J.x, dy = o.py - J.y, dz = o.pz - J.z;
+            const float r2 = dot3(dx, dy, dz, dx, dy, dz);
+            const float t = SMALLH ? __builtin_amdgcn_fmed3f(k.h2 - r2, 0.0f, 1.0f) : fmaxf(k.h2 - r2, 0.0f);
+            o.dsum = fmaf(t * t, t, o.dsum);
+        };
+        listed(density_at);
+        o.dsum = fmaf(k.h2 * k.h2, k.h2, o.dsum);
+        finish_density(k, o);
+    }
 #endif
     // ---- sweep 2 ----
     if (listOk) listed(force_at); else plain(force_plain);
