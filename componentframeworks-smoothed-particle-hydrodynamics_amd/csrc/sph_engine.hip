@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -484,13 +485,14 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
                                        e->debugFlags, e->d_stats);
                 behind = e->d_tileDone;
             }
-            auto walk = [&](hipStream_t st, const uint32_t* lo, const uint32_t* hi) {
+            auto walk = [&](hipStream_t st, const uint32_t* lo, const uint32_t* hi, bool bothEnds = false) {
+                const int dbg = (e->debugFlags & ~256) | (bothEnds ? 256 : 0);    // (bit 8: the launch covers [0, *lo) and [*hi, end) instead of [*lo, *hi))
                 if (k.h2 <= 1.0f)
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
+                                       e->d_order, e->d_cellStart, live, n, dbg, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
                 else
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, e->debugFlags, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
+                                       e->d_order, e->d_cellStart, live, n, dbg, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
             };
             // The pack of the next exchange only reads the slots of the kSlabDepth lowest / highest local cell layers (k_slab_pack,
             // under the same conditions): those two slot ranges first, the event, then everything in between.
@@ -510,13 +512,24 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
                 // profiles/r03_slab_face_launch_schedules.txt.)  Same inputs, disjoint output slots; the engine's stream joins the
                 // interior at the end of the pass.
 #ifndef SPH_SLAB_INTERIOR_AFTER
-#define SPH_SLAB_INTERIOR_AFTER 1     // 0: the interior starts with the first face launch, 1: after it (beside the second), 2: after both (no overlap)
+#define SPH_SLAB_INTERIOR_AFTER 0     // 0: the interior starts with the (first) face launch, 1: after the first of two (beside the second), 2: after the faces (no overlap)
 #endif
+#ifndef SPH_SLAB_MERGED_FACES
+#define SPH_SLAB_MERGED_FACES 1       // 1 (round 4): both face ranges in ONE launch (one tail instead of two); the interior then starts with it (INTERIOR_AFTER 0) or behind it (2).
+                                      // One rank's share of configs[4], bench.py --slab-path, 60 substeps: two launches + interior behind the first 1.351-1.355 ms,
+                                      // merged + interior at once 1.313-1.316, merged + interior behind 1.348-1.354 (profiles/r04_slab_face_launch_schedules.txt)
+#endif
+                if (SPH_SLAB_MERGED_FACES) {
+                    if (SPH_SLAB_INTERIOR_AFTER == 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                    walk(e->stream, endLo, startHi, true);
+                    if (SPH_SLAB_INTERIOR_AFTER != 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                } else {
                 if (SPH_SLAB_INTERIOR_AFTER == 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
                 walk(e->stream, nullptr, endLo);
                 if (SPH_SLAB_INTERIOR_AFTER == 1) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
                 walk(e->stream, startHi, nullptr);
                 if (SPH_SLAB_INTERIOR_AFTER == 2) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                }
                 HIP_TRY(hipEventRecord(e->evBoundary, e->stream));
                 HIP_TRY(hipStreamWaitEvent(e->bstream, e->evSorted, 0));
                 walk(e->bstream, endLo, startHi);
@@ -1355,7 +1368,11 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
 }
 
 // ---- message sizes: records in use two exchanges ago + a quarter + 1024, the face capacity until those counts exist ----
-static uint32_t msg_records(uint32_t seen, uint32_t cap) { return (uint32_t)std::min<uint64_t>(cap, (uint64_t)seen + seen / 4u + 1024u); }
+static uint32_t msg_records(uint32_t seen, uint32_t cap) {
+    static const char* tight = std::getenv("SPH_SLAB_MSG_MARGIN0");          // test hook: no margin at all, so that any growth shows as error flag 8
+    if (tight && tight[0] == '1') return std::min(cap, seen);
+    return (uint32_t)std::min<uint64_t>(cap, (uint64_t)seen + seen / 4u + 1024u);
+}
 static int slab_size_messages(SphEngine* e) {
     for (int i = 0; i < 4; ++i) e->msgSend[i] = e->msgRecv[i] = e->faceCap;
     if (e->exchangeNo >= 2) {

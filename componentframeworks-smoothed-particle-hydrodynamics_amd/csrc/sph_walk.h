@@ -120,12 +120,23 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     // XCD-aware block mapping as in k_sph_list: blocks b and b + 8 share an XCD, each XCD walks one contiguous eighth of the LIVE slots.
     // A launch may cover only the slot range [*rangeLo, *rangeHi) (device-side bounds, nullptr = open end): a z-slab engine
     // runs the slots next to its faces first, so that the halo exchange can start while the interior is still being computed.
+    // dbg bit 8 (256): the launch covers BOTH ENDS instead, [0, *rangeLo) and [*rangeHi, live count), in one grid (one tail instead of two).
     const int boundAll = liveCount ? min(n, (int)*liveCount) : n;
-    const int first = rangeLo ? min((int)*rangeLo, boundAll) : 0;
-    const int bound = rangeHi ? min((int)*rangeHi, boundAll) : boundAll;
-    const int nBlocks = (max(bound - first, 0) + kB - 1) / kB, perXcd = (nBlocks + 7) >> 3;
-    const int vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
-    if (((int)blockIdx.x >> 3) >= perXcd || vb >= nBlocks) return;   // whole block, uniformly
+    const bool ends = (dbg & 256) != 0;
+    int first = (rangeLo && !ends) ? min((int)*rangeLo, boundAll) : 0;
+    int bound = rangeHi ? min((int)*rangeHi, boundAll) : boundAll;
+    int vb;
+    if (!ends) {
+        const int nBlocks = (max(bound - first, 0) + kB - 1) / kB, perXcd = (nBlocks + 7) >> 3;
+        vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
+        if (((int)blockIdx.x >> 3) >= perXcd || vb >= nBlocks) return;   // whole block, uniformly
+    } else {
+        const int endLo = min((int)*rangeLo, boundAll), startHi = max(bound, endLo);
+        const int nLo = (endLo + kB - 1) / kB, nHi = (max(boundAll - startHi, 0) + kB - 1) / kB, perXcd = (nLo + nHi + 7) >> 3;
+        vb = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
+        if (((int)blockIdx.x >> 3) >= perXcd || vb >= nLo + nHi) return;
+        if (vb < nLo) { first = 0; bound = endLo; } else { first = startHi; bound = boundAll; vb -= nLo; }
+    }
     const int sRaw = first + vb * kB + tid;
     bool live = sRaw < bound;                              // every lane stays to the end (the staging is a wave-wide cooperation)
     const int s = live ? sRaw : max(bound - 1, 0);

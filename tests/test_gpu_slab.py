@@ -504,3 +504,39 @@ def test_step_times_say_whether_the_exchange_was_hidden(pkg, oracle):
     for s in grp.sims:
         pack, transfer, unpack, exchange_end, pass_end = s.engine.step_times()
         assert pack > 0 and transfer >= 0 and unpack > 0 and exchange_end > 0 and pass_end > 0
+
+
+def test_a_message_that_turns_out_too_small_is_reported(pkg, oracle):
+    """Messages are sized from the counts of two exchanges ago + 25 % + 1024 records.  With the margin taken away (test hook
+    SPH_SLAB_MSG_MARGIN0=1, read when the library first sizes a message: own process) any growth of a face's record count cuts
+    records off -- which must be LOUD (error flag 8: sph_slab_status / sph_slab_download fail), never silent."""
+    import subprocess
+    code = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import PKG_NAME, small_scene, to_oracle_params
+pkg = importlib.import_module(PKG_NAME)
+halo = importlib.import_module(PKG_NAME + ".halo")
+import torch
+rec, sp = small_scene(pkg, n=6000, grid=20, seed=51)
+g = pkg.compute_grid_extents(sp)
+cz = np.clip(np.floor(((rec["pos"][:, 2] - np.float32(g.gridMin[2])) / np.float32(g.cellSize)).astype(np.float32)), 0, g.dims[2] - 1).astype(np.int64)
+ids = np.arange(len(rec), dtype=np.uint32)
+mk = lambda p, i, prm, z0, z1, lo, hi: halo.HipSlabEngine(p, i, prm, z0, z1, lo, hi, capacity=len(rec) * 2 + 8192)
+grp = halo.SlabGroup.from_particles(rec, ids, sp, tuple(g.dims), 2, mk, lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), 8192, cz)
+grp.enable_overlap(8192)
+for s in range(8):
+    if s == 4:
+        grp.ApplyWaveImpulse(40.0, 50.0, 1.0, (0.0, 0.0, 1.0), -1e9, 1e9)      # a kick along z: the faces' record counts change
+    grp.DispatchCompute()
+try:
+    for x in grp.sims:
+        x.engine.status()
+    print("SILENT")
+except pkg.SphError as ex:
+    print("LOUD", ex)
+''' % ROOT
+    env = dict(os.environ, SPH_SLAB_MSG_MARGIN0="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert "LOUD" in res.stdout and "more halo records than its message" in res.stdout, res.stdout + res.stderr

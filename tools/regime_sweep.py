@@ -42,10 +42,10 @@ step = 0
 while step <= last:
     row = {"step": step}
     for kind in kinds:
-        row[{3: "walk", 2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
+        row[{4: "tile", 3: "walk", 2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
         step += REPS
     print(json.dumps(row), flush=True)
-    select(2)
+    select(3)
     rest = max(0, stride - REPS * len(kinds))
     f.DispatchN(rest)
     step += rest
