@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 passes over EXACTLY the command bench.py's headline comes from, summarised for exactly its timed launches
 # (launches W .. W+K-1 of the SPH kernel): kernel-trace average + HBM bytes + VALU instructions + L1 cache-line accesses.
-# usage (on the GPU box): bash tools/profile_bench.sh [steps=50] [warmup=5] [kernel=k_sph_walk] [tag=r03]
+# usage (on the GPU box): bash tools/profile_bench.sh [steps=50] [warmup=5] [kernel=k_sph_walk] [tag=r04]
 #   -> gpurun_out/<tag>_bench_*.json (copy to profiles/)
 set -e
-K=${1:-50}; W=${2:-5}; KN=${3:-k_sph_walk}; TAG=${4:-r03}
+K=${1:-50}; W=${2:-5}; KN=${3:-k_sph_walk}; TAG=${4:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CMD="python3 $R/bench.py --steps $K --warmup $W --no-cpu-baseline --no-breakdown"
 cd /tmp && export TMPDIR=/tmp
