@@ -132,7 +132,8 @@ enum {
     /* test / tuning hooks */
     SPH_OPT_DEBUG = 100          /* test hooks of k_sph_walk / k_sph_list -- bit 0: treat every neighbour list as overflowed, bit 1: treat every target as
                                     outside the list's slack (sweep-3 fallback), bit 2: treat every window as overflowed (whole wave falls
-                                    back), bit 3: count fallbacks / list entries / staged candidates for sph_debug_counters */
+                                    back), bit 3: count fallbacks / list entries / staged candidates for sph_debug_counters, bit 4 (16): k_sph_tile leaves every block of cells to k_sph_walk
+                                    (bit 8 is used internally by the z-slab face launch) */
 };
 
 /* ---- host-only helpers (no device needed) --------------------------------------- */
