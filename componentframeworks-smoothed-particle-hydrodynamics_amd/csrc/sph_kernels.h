@@ -890,62 +890,11 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
     if (slab_record_misplaced(g, r, fromLo != 0)) atomicOr(&counters[4], 16u);
 }
 
-// ---- exchange without host round trips: the record count travels in a header record in front of the payload ----
-constexpr uint32_t kSlabMagic = 0x48414c4fu;            // "HALO" in the header's flags word
-// counters: [0] records for the lower neighbour, [1] for the upper one, [2] slots in use, [4] error flags
-// (bit 0: a send buffer overflowed, bit 1: the slab's slot capacity overflowed on unpack, bits 2-3: k_slab_commit,
-// bit 4: a received particle had moved more than one cell layer, slab_record_misplaced).
-__global__ void k_slab_headers(uint32_t* __restrict__ counters, SlabRec* __restrict__ sendLo, SlabRec* __restrict__ sendHi, uint32_t capLo, uint32_t capHi) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t nl = counters[0], nh = counters[1];
-    if (nl > capLo || nh > capHi) atomicOr(&counters[4], 1u);
-    if (sendLo) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = h.ax = h.ay = h.az = h.pad2 = 0.0f; h.id = min(nl, capLo); h.flags = kSlabMagic; h.pad = nl; sendLo[0] = h; }
-    if (sendHi) { SlabRec h; h.px = h.py = h.pz = h.vx = h.vy = h.vz = h.rho = h.prs = h.foam = h.ax = h.ay = h.az = h.pad2 = 0.0f; h.id = min(nh, capHi); h.flags = kSlabMagic; h.pad = nh; sendHi[0] = h; }
-    counters[5] = nl; counters[6] = nh;                 // what sph_slab_status reports
-    counters[0] = 0u; counters[1] = 0u;                 // ready for the next k_slab_pack (no memset between substeps)
-}
-// A received header is trusted only as far as it can be checked: the magic must be there and the count must fit the
-// message; anything else counts as an empty message (k_slab_commit raises the error bit).
-__device__ __forceinline__ uint32_t slab_header_count(const SlabRec* __restrict__ recv, uint32_t recvCap) {
-    const SlabRec h = recv[0];
-    return (h.flags == kSlabMagic && h.id <= recvCap) ? h.id : 0u;
-}
-// recv[0] is the header (id = record count), recv[1..] the payload; appended behind slot counters[2] (+ the other
-// direction's count when `afterOther` points at that header).
-__global__ __launch_bounds__(kBlock) void k_slab_unpack_dev(const SlabRec* __restrict__ recv, const SlabRec* __restrict__ afterOther, uint32_t recvCap,
-                                                            float4* __restrict__ pos, float4* __restrict__ vel, float2* __restrict__ rp,
-                                                            float* __restrict__ foam, float4* __restrict__ acc, uint32_t* __restrict__ counters, uint32_t slotCap,
-                                                            SlabGeom g, int fromLo) {
-    const uint32_t cnt = slab_header_count(recv, recvCap);
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= cnt) return;
-    const uint32_t base = counters[2] + (afterOther ? slab_header_count(afterOther, recvCap) : 0u);
-    const uint32_t d = base + i;
-    if (d >= slotCap) { atomicOr(&counters[4], 2u); return; }
-    const SlabRec r = recv[1 + i];
-    pos[d] = make_float4(r.px, r.py, r.pz, bitsf(r.flags));
-    vel[d] = make_float4(r.vx, r.vy, r.vz, bitsf(r.id));
-    rp[d] = make_float2(r.rho, r.prs);
-    foam[d] = r.foam;
-    acc[d] = make_float4(r.ax, r.ay, r.az, 0.0f);
-    if (slab_record_misplaced(g, r, fromLo != 0)) atomicOr(&counters[4], 16u);
-}
-// counters[4] bit 2: a received header was not a header (magic / count); bit 3: the SENDER had more records than its
-// message could carry (header.pad = its true count), i.e. the neighbour's overflow made visible on this rank too.
-__global__ void k_slab_commit(uint32_t* __restrict__ counters, const SlabRec* __restrict__ recvLo, const SlabRec* __restrict__ recvHi, uint32_t slotCap,
-                              uint32_t recvCap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t add = 0u, err = 0u;
-    for (const SlabRec* r : {recvLo, recvHi}) {
-        if (!r) continue;
-        const SlabRec h = r[0];
-        if (h.flags != kSlabMagic || h.id > recvCap) err |= 4u;
-        else { add += h.id; if (h.pad > h.id) err |= 8u; }
-    }
-    if (err) atomicOr(&counters[4], err);
-    counters[2] = min(counters[2] + add, slotCap);
-}
-
+// ---- exchange without host round trips: the record counts travel in a header in front of the payload ----
+constexpr uint32_t kSlabMagic = 0x48414c4fu;            // "HALO": first word of a face's header
+// counters[4], the exchange's flags -- bit 0: a send face overflowed, bit 1: the slab's slot capacity overflowed on unpack, bit 2: a received
+// face did not start with a valid header, bit 3: the sender had more records than its message carried, bit 4 (16, a notice): a particle crossed more
+// cell layers within one substep than the exchange follows (slab_check_layer_move, slab_record_misplaced).
 // ---- round 4: the compact faces (SlabFace layout above).  counters: [8] halo copies for lo, [9] for hi, [10] migrants for lo, [11] for hi
 // (running, reset here), [12..15] the same four of the last pack (sph_slab_status / the host's message sizing), [7] exchanges so far.
 __global__ void k_slab_headers2(uint32_t* __restrict__ counters, char* __restrict__ faceLo, char* __restrict__ faceHi, uint32_t cap) {
