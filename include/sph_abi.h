@@ -284,10 +284,12 @@ int sph_slab_download(SphEngine* e, void* hostOut, size_t capRecords, size_t* nO
  * then faceCap 40-byte records for HALO COPIES (float px,py,pz,vx,vy,vz,rho,prs; uint32 id, flags: what a neighbour candidate
  * needs -- round 4).  Counts never travel through the host.  Per substep a rank calls sph_slab_exchange
  * (pack -> per z-neighbour two grouped ncclSend / ncclRecv pairs over xGMI: header + migrants in use, halo copies in use ->
- * unpack, all on the engine's stream) and then sph_dispatch.  MESSAGE SIZES: the records in use two exchanges ago + a quarter
- * + 1024 (read back asynchronously into pinned memory, so the path never waits for the device; both ends of a link derive the
- * size from the same number: the sender from its own count, the receiver from the header it received then), the whole face for
- * the first two exchanges.  A message that turns out too small sets error flag 8 on the receiver (records were cut off).
+ * unpack, all on the engine's stream) and then sph_dispatch.  MESSAGE SIZES: the whole face, unless the face has been calm (its
+ * record counts of the last two known exchanges within 3 % of each other, no impulse / container edit / re-priming in the last
+ * three exchanges): then the records in use two exchanges ago + a quarter + 1024 (read back asynchronously into pinned memory,
+ * so the path never waits for the device; both ends of a link derive the size from the same numbers: the sender from its own
+ * counts, the receiver from the headers it received then).  A message that turns out too small sets error flag 8 on the
+ * receiver (records were cut off).
  * sph_slab_pack_async / sph_slab_unpack_async are the two halves for hosts that move the faces themselves (several slab
  * engines in one process, another transport): move sph_slab_face_bytes() bytes, or the three parts in use.  Overflows (send
  * face, slot capacity) set a device-side flag that sph_slab_status / sph_slab_download report.  faceCap must be the same on
