@@ -344,9 +344,10 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     }
     {
         Timed t(e, SPH_K_SCAN);
-        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, C);
-        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kBlock), 0, e->stream, e->d_blockSums, sb, e->d_nFallback);
-        hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, e->d_cellStart, C, (uint32_t)n);
+        const int rawSums = sb <= kScanFusedBlocks ? 1 : 0;
+        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, C, e->d_nFallback);
+        if (!rawSums) hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kBlock), 0, e->stream, e->d_blockSums, sb);
+        hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, e->d_cellStart, C, (uint32_t)n, rawSums);
     }
     if (n) {
         Timed t(e, SPH_K_SCATTER);

@@ -121,8 +121,9 @@ __device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, in
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ blockSums, int numCells) {
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ blockSums, int numCells, uint32_t* __restrict__ zeroMe) {
     __shared__ uint32_t sm[4];
+    if (zeroMe && blockIdx.x == 0 && threadIdx.x == 0) *zeroMe = 0u;   // k_sph_tile's count of blocks of cells left to k_sph_walk (per substep)
     const int c0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
     scan_load16(cnt, c0, numCells, v);
@@ -135,9 +136,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restri
 }
 
 // single block: exclusive scan of the per-block sums (any count, chunks of 256 with carry)
-__global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict__ blockSums, int numBlocks, uint32_t* __restrict__ zeroMe) {
+__global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict__ blockSums, int numBlocks) {
     __shared__ uint32_t sm[4];
-    if (zeroMe && threadIdx.x == 0) *zeroMe = 0u;          // k_sph_tile's count of blocks of cells left to k_sph_walk (per substep)
     uint32_t carry = 0;
     for (int base = 0; base < numBlocks; base += kBlock) {
         int i = base + threadIdx.x;
@@ -150,9 +150,22 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict_
 }
 
 // per-block scan + block offset -> cellStart[0..numCells]; clears the histogram (ClearGrid)
+// rawSums (round 4, grids of up to kScanFusedBlocks tiles): blockSums still holds k_scan_reduce's per-tile totals and every block adds up the
+// totals in front of its own (a few hundred words out of L2), which saves the single-block k_scan_blocksums launch in between.
+constexpr int kScanFusedBlocks = 1024;
 __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ blockSums,
-                                                       uint32_t* __restrict__ cellStart, int numCells, uint32_t nTotal) {
+                                                       uint32_t* __restrict__ cellStart, int numCells, uint32_t nTotal, int rawSums) {
     __shared__ uint32_t sm[4];
+    uint32_t before = 0u;
+    if (rawSums) {
+        uint32_t part = 0u;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += blockSums[i];
+        uint32_t tot;
+        (void)block_excl_scan(part, sm, tot);
+        before = tot;
+    } else {
+        before = blockSums[blockIdx.x];
+    }
     const int c0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
     scan_load16(cnt, c0, numCells, v);
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cn
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) { const uint32_t t = v[j]; v[j] = s; s += t; }       // exclusive prefix inside the thread
     uint32_t total;
-    const uint32_t off = blockSums[blockIdx.x] + block_excl_scan(s, sm, total);
+    const uint32_t off = before + block_excl_scan(s, sm, total);
     if (c0 + kScanItems <= numCells) {
         uint4* ps = reinterpret_cast<uint4*>(cellStart + c0);
         uint4* pc = reinterpret_cast<uint4*>(cnt + c0);
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cn
     }
     // total = live particles (in z-slab mode nTotal, the slot count, also covers dead slots)
     (void)nTotal;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) cellStart[numCells] = blockSums[blockIdx.x] + total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) cellStart[numCells] = before + total;
 }
 
 // ---- counting-sort scatter: tmp[slot] = (particle id, source index) ---------------------
