@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -63,6 +64,7 @@ inline int blocks_for(size_t n, int per = sph::kBlock) { return (int)((n + per -
 
 struct SphEngine;
 static std::set<SphEngine*> g_engines;      // live engines of this process (sph_destroy clears what neighbours hold of a destroyed one)
+static std::mutex g_enginesMutex;           // (a host may drive its engines from one thread each)
 
 struct SphEngine {
     hipStream_t stream = nullptr;
@@ -710,7 +712,7 @@ static int create_common(SphEngine** out, const SphParams* params, void* stream,
         e->ownStream = true;
     }
     *made = e;
-    g_engines.insert(e);
+    { std::lock_guard<std::mutex> lk(g_enginesMutex); g_engines.insert(e); }
     return SPH_OK;
 }
 
@@ -754,9 +756,12 @@ int sph_destroy(SphEngine* e) {
     for (auto& ev : e->evPool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->xstream) { (void)hipStreamSynchronize(e->xstream); (void)hipStreamDestroy(e->xstream); }
     if (e->bstream) { (void)hipStreamSynchronize(e->bstream); (void)hipStreamDestroy(e->bstream); }
-    for (SphEngine* o : g_engines)                                            // a neighbour engine of this process must not wait for an event that is gone
-        for (auto& pd : o->peerDone) if (pd && pd == e->evDone) pd = nullptr;
-    g_engines.erase(e);
+    {
+        std::lock_guard<std::mutex> lk(g_enginesMutex);
+        for (SphEngine* o : g_engines)                                        // a neighbour engine of this process must not wait for an event that is gone
+            for (auto& pd : o->peerDone) if (pd && pd == e->evDone) pd = nullptr;
+        g_engines.erase(e);
+    }
     for (hipEvent_t ev : {e->evBoundary, e->evPacked, e->evDone, e->evSorted, e->evInterior, e->evPassEnd}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->evX) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->evCnt) if (ev) (void)hipEventDestroy(ev);
