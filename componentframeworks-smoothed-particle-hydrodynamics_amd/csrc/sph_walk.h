@@ -36,6 +36,9 @@ namespace sph {
 #define SPH_WALK_REORDER 0   // 1: after sweep 1 the block's targets are handed to the lanes in order of their list length (round 4 experiment, bit-exact,
                              // NOT faster: 446 -> 515 us, profiles/r04_walk_reorder_experiment.txt: a wave of scattered targets gathers from 4x the cache lines)
 #endif
+#ifndef SPH_WALK_PACKED
+#define SPH_WALK_PACKED 0    // 1: sweep 1 takes two staged candidates per step out of structure-of-arrays windows, the distance and the list test as v_pk_*_f32 (round 4 experiment, section 11.2)
+#endif
 #ifndef SPH_WALK_EPS
 #define SPH_WALK_EPS 0.04f   // slack of the list around the predicted position, in units of h (0.03 / 0.04 / 0.06 / 0.08: 442 / 441 / 451 / 463 us)
 #endif
@@ -238,12 +241,23 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         const uint32_t A = aN, B = bN;
         const bool staged = stagedN;
         const bool selfRow = (r == 4);
+#if SPH_WALK_PACKED
+        float* const wx = reinterpret_cast<float*>(&stage[wv][0]);           // the window as three arrays: two consecutive candidates' x (y, z) sit side by side
+        float* const wy = wx + CAP;
+        float* const wz = wy + CAP;
+        if (mne != 0ull && staged) {
+            wx[lane] = pre0.x; wy[lane] = pre0.y; wz[lane] = pre0.z;
+            if (CAP > 64 && (CAP >= 128 || lane < CAP - 64)) { wx[lane + 64] = pre1.x; wy[lane + 64] = pre1.y; wz[lane + 64] = pre1.z; }
+            if (CAP > 128 && lane < CAP - 128) { wx[lane + 128] = pre2.x; wy[lane + 128] = pre2.y; wz[lane + 128] = pre2.z; }
+        }
+#else
         if (mne != 0ull && staged) {                       // this row's window into LDS (lanes past the union store duplicates)
             const uint32_t e0 = ((uint32_t)r << 12) | ((uint32_t)lane << 4);
             stage[wv][lane] = make_float4(pre0.x, pre0.y, pre0.z, bitsf(e0));
             if (CAP > 64 && (CAP >= 128 || lane < CAP - 64)) stage[wv][lane + 64] = make_float4(pre1.x, pre1.y, pre1.z, bitsf(e0 + (64u << 4)));
             if (CAP > 128 && lane < CAP - 128) stage[wv][lane + 128] = make_float4(pre2.x, pre2.y, pre2.z, bitsf(e0 + (128u << 4)));
         }
+#endif
         if (r < 8) plan(qs[r + 1], qe[r + 1]);
         if (mne == 0ull) continue;
         nRows += 1; nUnstaged += staged ? 0 : 1;           // (wave-uniform; diagnostics only)
@@ -252,6 +266,42 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         if (B - A > 255u) listOk = false;                  // offsets beyond the entry format (wave-uniform)
         const uint32_t off = ne ? q0 - A : 0u;
         if (selfRow) eSelf = (4u << 12) | ((((uint32_t)s - A) << 4) & 0xff0u);
+#if SPH_WALK_PACKED
+        if (staged) {
+            __builtin_amdgcn_wave_barrier();
+            const float* __restrict__ px = wx + off;
+            const float* __restrict__ py = wy + off;
+            const float* __restrict__ pz = wz + off;
+            uint32_t e = ((uint32_t)r << 12) | (off << 4);
+            uint32_t m = 0;
+            for (; m + 2u <= len; m += 2u, e += 32u) {
+                const v2f X = {px[m], px[m + 1u]}, Y = {py[m], py[m + 1u]}, Z = {pz[m], pz[m + 1u]};
+                cur = min(cur, curEnd);
+                // two candidates: the same operations as visit(), each half of a packed instruction rounds like the scalar one; the density sum and the list stay sequential
+                const v2f dx = o.px - X, dy = o.py - Y, dz = o.pz - Z;
+                const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                const v2f hm = k.h2 - r2;
+                const v2f t = {SMALLH ? __builtin_amdgcn_fmed3f(hm.x, 0.0f, 1.0f) : fmaxf(hm.x, 0.0f), SMALLH ? __builtin_amdgcn_fmed3f(hm.y, 0.0f, 1.0f) : fmaxf(hm.y, 0.0f)};
+                const v2f tt = t * t;
+                o.dsum = fmaf(tt.x, t.x, o.dsum);
+                o.dsum = fmaf(tt.y, t.y, o.dsum);
+                const v2f ez2 = {ez, ez}, ey2 = {ey, ey}, ex2 = {ex, ex}, nb2 = {-kBig, -kBig};
+                const v2f w = __builtin_elementwise_fma(ez2, dz, __builtin_elementwise_fma(ey2, dy, __builtin_elementwise_fma(ex2, dx, r2 + c0)));
+                v2f sg = __builtin_elementwise_fma(nb2, t, w);
+                if (selfRow) { sg.x = (e == eSelf) ? 1.0f : sg.x; sg.y = (e + 16u == eSelf) ? 1.0f : sg.y; }
+                *reinterpret_cast<uint16_t*>(nlBytes + cur) = (uint16_t)e;
+                cur += (fbits(sg.x) >> 22) & adv;
+                *reinterpret_cast<uint16_t*>(nlBytes + cur) = (uint16_t)(e + 16u);
+                cur += (fbits(sg.y) >> 22) & adv;
+            }
+            if (m < len) {
+                const float4 J = make_float4(px[m], py[m], pz[m], 0.0f);
+                cur = min(cur, curEnd);
+                visit(J, e, selfRow);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else
+#endif
         if (staged) {
             __builtin_amdgcn_wave_barrier();
             const float4* __restrict__ wp = &stage[wv][off];
