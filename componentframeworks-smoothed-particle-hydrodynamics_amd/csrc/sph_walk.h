@@ -39,6 +39,10 @@ namespace sph {
 #ifndef SPH_WALK_PACKED
 #define SPH_WALK_PACKED 0    // 1: sweep 1 takes two staged candidates per step out of structure-of-arrays windows, the distance and the list test as v_pk_*_f32 (round 4 experiment, section 11.2)
 #endif
+#ifndef SPH_WALK_STAGE_RSRC
+#define SPH_WALK_STAGE_RSRC 1  // 1 (round 4): the windows' loads as bounds-checked buffer loads over a per-row resource [A, B): no per-lane clamp, no 64-bit address arithmetic
+                               // (443-445 us against 447-449 with clamped global loads, gpurun_out/abw_rs.log -> profiles/r04_walk_stage_rsrc.txt)
+#endif
 #ifndef SPH_WALK_EPS
 #define SPH_WALK_EPS 0.04f   // slack of the list around the predicted position, in units of h (0.03 / 0.04 / 0.06 / 0.08: 442 / 441 / 451 / 463 us)
 #endif
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     uint32_t aN = 0u, bN = 0u;
     bool stagedN = false;
     float4 pre0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre1 = pre0, pre2 = pre0;
+    const uint32_t laneOff32 = (uint32_t)lane * 32u;
     auto plan = [&](uint32_t q0, uint32_t q1) {
         const bool ne = q1 > q0;
         mneN = __ballot(ne);
@@ -217,11 +222,20 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
         aN = A; bN = B;
         stagedN = (B - A) <= (uint32_t)CAP && !(dbg & 4);  // wave-uniform
+#if SPH_WALK_STAGE_RSRC
+        if (stagedN) {                                     // the window's loads through a buffer resource over exactly [A, B): no per-lane clamp or 64-bit address, a load past B returns 0 (never read)
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(S.pv + 2u * (size_t)A), 0, (int)((B - A) * 32u), 0x00020000);
+            pre0 = buf_load4(rw, laneOff32);
+            if (CAP > 64) pre1 = buf_load4(rw, laneOff32 + 2048u);
+            if (CAP > 128) pre2 = buf_load4(rw, laneOff32 + 4096u);
+        }
+#else
         if (stagedN) {                                     // clamped, unconditional: B - A >= 1 here
             pre0 = S.P(A + min((uint32_t)lane, B - A - 1u));
             if (CAP > 64) pre1 = S.P(A + min((uint32_t)lane + 64u, B - A - 1u));
             if (CAP > 128) pre2 = S.P(A + min((uint32_t)lane + 128u, B - A - 1u));
         }
+#endif
     };
     int nRows = 0, nUnstaged = 0;
 #if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
