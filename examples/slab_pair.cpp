@@ -92,7 +92,14 @@ int main(int argc, char** argv) {
             if (((int)q >= zmid ? 1 : 0) != (ids[0].size() > out[i].id && std::binary_search(ids[0].begin(), ids[0].end(), out[i].id) ? 0 : 1)) ++moved;
         }
         got += m;
-        std::printf("slab %d: %zu owned particles, last pack %u / %u records\n", r, m, st[0], st[1]);
+        uint64_t bytes[4];
+        CHECK(sph_slab_message_bytes(slab[r], bytes));       // what the last exchange sent to the lower / upper neighbour, against a whole face
+        if (st[4] & 16u) {                                    // notice: a particle crossed more cell layers in one substep than the exchange follows
+            std::printf("slab %d: notice 16 (a particle crossed more than 3 cell layers in one substep)\n", r);
+            CHECK(sph_slab_clear_flags(slab[r], 16u));
+        }
+        std::printf("slab %d: %zu owned particles, last pack %u / %u records, last messages %llu / %llu bytes (a face: %llu)\n", r, m, st[0], st[1],
+                    (unsigned long long)bytes[0], (unsigned long long)bytes[1], (unsigned long long)(bytes[2] ? bytes[2] : bytes[3]));
     }
     std::printf("%zu of %zu particles, %zu differ from the single engine, %zu changed slab\n", got, n, bad, moved);
     for (auto* e : slab) sph_destroy(e);
