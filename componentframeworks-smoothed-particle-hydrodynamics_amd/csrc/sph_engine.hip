@@ -938,7 +938,9 @@ int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, floa
     else { w.ndx = 0.0f; w.ndy = 1.0f; w.ndz = 0.0f; }
     w.amplitude = amplitude; w.kk = 6.28318530718f / wavelength; w.phase = phase; w.yMin = yMin; w.yMax = yMax;
     const size_t nw = e->slab ? e->nSlots : e->n;
-    e->calmHold = 3;
+    // z-slabs: a kick of A changes a particle's step by at most A dt, i.e. a face layer's record count by about A dt / h per substep: a gentle wave (the
+    // scene's A = 1.5: 0.5 % of h per substep) leaves a calm face calm; anything that could outgrow the messages' margin within two exchanges holds them whole
+    if (std::fabs(amplitude) * e->params.param_timeStep > 0.02f * e->params.param_h) e->calmHold = 3;
     if (nw) {
         Timed t(e, SPH_K_IMPULSE);
         hipLaunchKernelGGL(k_wave_impulse, dim3(blocks_for(nw)), dim3(kBlock), 0, e->stream, w, e->d_pos[e->cur], e->d_vel[e->cur],
