@@ -37,7 +37,7 @@ for s in range(steps):
         for x in grp.sims:
             try:
                 st = x.engine.status()
-                msgs.append(st)
+                msgs.append(st + [x.engine.message_bytes()[:2]])      # flags + the bytes the last exchange sent to lo / hi (a whole face: message_bytes()[2])
             except pkg.SphError as ex:
                 msgs.append(str(ex)[:90])
                 first_report = first_report or s + 1
