@@ -1394,6 +1394,8 @@ static uint32_t msg_records(uint32_t seen, uint32_t before, uint32_t cap) {
     if (hi - lo > hi / 32u + 64u) return cap;                                // not calm: the whole face
     return (uint32_t)std::min<uint64_t>(cap, (uint64_t)seen + seen / 4u + 1024u);
 }
+// host-only: the rule above as a function of (count two exchanges ago, count three exchanges ago, face capacity)
+int sph_slab_message_records(uint32_t seen, uint32_t before, uint32_t cap) { return (int)msg_records(seen, before, cap); }
 static int slab_size_messages(SphEngine* e) {
     for (int i = 0; i < 4; ++i) e->msgSend[i] = e->msgRecv[i] = e->faceCap;
     const bool hold = e->calmHold > 0;                      // (host-side knowledge, the same on every rank: impulses, container edits and re-priming are collective)

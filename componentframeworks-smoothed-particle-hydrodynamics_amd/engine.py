@@ -91,7 +91,7 @@ ABI_SYMBOLS = (
     "sph_slab_alloc_faces", "sph_slab_face_buffer", "sph_slab_pack_async", "sph_slab_unpack_async", "sph_slab_status",
     "sph_comm_unique_id", "sph_comm_create", "sph_comm_destroy", "sph_comm_selftest", "sph_comm_selftest_timed", "sph_slab_exchange",
     "sph_slab_step_begin", "sph_slab_step_finish", "sph_slab_step_finish_local",
-    "sph_slab_face_bytes", "sph_slab_clear_flags", "sph_slab_message_bytes", "sph_slab_step_times",
+    "sph_slab_face_bytes", "sph_slab_clear_flags", "sph_slab_message_bytes", "sph_slab_message_records", "sph_slab_step_times",
     "sph_river_default", "sph_generate_river_terrain", "sph_spawn_river_particles", "sph_set_river", "sph_get_river",
 )
 # sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_walk / k_sph_list, summed over launches:
@@ -194,6 +194,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_slab_clear_flags.argtypes = [vp, C.c_uint32]
     L.sph_slab_message_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sph_slab_step_times.argtypes = [vp, C.POINTER(C.c_float)]
+    L.sph_slab_message_records.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.sph_river_default.argtypes = [C.POINTER(SphRiver)]
     L.sph_generate_river_terrain.argtypes = [pp, C.c_int, C.POINTER(SphRiver), vp]
     L.sph_spawn_river_particles.argtypes = [pp, C.POINTER(SphRiver), vp, C.c_size_t, C.c_uint32, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]

@@ -323,6 +323,9 @@ int sph_slab_clear_flags(SphEngine* e, uint32_t mask);
 /* Bytes of the last exchange's messages to the lower / upper neighbour, and the bytes a whole face would be: {sent lo, sent hi,
  * face lo, face hi} (host-side bookkeeping, no synchronisation). */
 int sph_slab_message_bytes(SphEngine* e, uint64_t out[4]);
+/* Host-only (no device): the sizing rule itself -- records a message carries, given the face's record count two exchanges ago, three
+ * exchanges ago, and the face capacity: the capacity unless the two counts are within 3 % + 64 of each other, else count + 25 % + 1024. */
+int sph_slab_message_records(uint32_t seen, uint32_t before, uint32_t cap);
 /* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy: rank 0 creates the id and hands its 128 bytes to the other ranks
  * by any means (MPI, a file, torch.distributed); one rank per process, on the current HIP device. */
 int sph_comm_unique_id(void* out128);

@@ -84,3 +84,18 @@ def test_python_mirror_surface(pkg):
                    "param_boxHalf", "param_boxEulerDeg", "param_shapeType", "param_shapeAux", "param_mixPattern",
                    "param_dyePattern", "param_wallRestitution", "param_wallFriction"]
     assert [f[0] for f in pkg.SphParams._fields_][:-1] == ref_members
+
+
+def test_slab_message_sizing_rule(pkg):
+    """The z-slab exchange sizes a message from counts that both ends of a link know (host-only rule, no device): whole faces
+    unless the face's record count was calm over the last two known exchanges, then count + 25 % + 1024, never above the capacity."""
+    L = pkg.load_library()
+    f = L.sph_slab_message_records
+    cap = 200000
+    assert f(100000, 100500, cap) == 100000 + 25000 + 1024            # calm (0.5 %): the records in use + a quarter + 1024
+    assert f(100000, 104000, cap) == cap and f(104000, 100000, cap) == cap   # 4 % apart: not calm, the whole face
+    assert f(190000, 190000, cap) == cap                               # the margin never exceeds the capacity
+    assert f(0, 0, cap) == 1024 and f(10, 70, cap) == 10 + 2 + 1024    # small faces: the absolute slack of 64 records counts as calm
+    assert f(10, 200, cap) == cap
+    for seen, before in ((5000, 5100), (5100, 5000), (123456, 120000)):
+        assert 0 < f(seen, before, cap) <= cap
