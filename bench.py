@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="auto", help="auto (config3 at N = 1, weak5 at N > 1) | config2 | config3 | weak5 (BASELINE configs[4] slab)")
     ap.add_argument("--settled-after", type=int, default=300, help="N = 1: after the timed run, continue the SAME run to this substep and record the settled regime (0 = skip)")
-    ap.add_argument("--neighbor", type=int, default=3, help="SPH pass: 3 = k_sph_walk (engine default), 2 = k_sph_list (round 2), 1 = k_sph_slow (plain per-target sweeps)")
+    ap.add_argument("--neighbor", type=int, default=3, choices=(1, 2, 3), help="SPH pass: 3 = k_sph_walk (engine default), 2 = k_sph_list (round 2), 1 = k_sph_slow (plain per-target sweeps)")
     ap.add_argument("--aos", default="lazy", choices=["eager", "lazy"], help="lazy (engine default): the 80-byte records are materialised once per frame; eager: by every substep")
     ap.add_argument("--frame-substeps", type=int, default=16, help="lazy, N = 1: materialise the 80-byte record array (sph_device_particles, what a renderer binds) after every this many "
                     "substeps INSIDE the timed region (Scene0p.h:48 maxSubstepsPerFrame = 16) and once more at its end")

@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libsph_hip.so")
 SOURCES = ["sph_engine.hip"]
-HEADERS = ["sph_device.h", "sph_host.h", "sph_kernels.h", "sph_pass.h", "sph_walk.h", "sph_tile.h", "sph_shapes_ext.h", os.path.join("..", "..", "include", "sph_abi.h")]
+HEADERS = ["sph_device.h", "sph_host.h", "sph_kernels.h", "sph_pass.h", "sph_walk.h", "sph_shapes_ext.h", os.path.join("..", "..", "include", "sph_abi.h")]
 
 # -ffp-contract=off: the arithmetic contract (DESIGN.md "Numerics") fixes where fmaf() is
 # used; the compiler must not fuse anything else.  Division / sqrt stay at hipcc's

@@ -19,8 +19,7 @@
 #include "../../include/sph_abi.h"
 #include "sph_host.h"
 #include "sph_kernels.h"
-#include "sph_pass.h"
-#include "sph_tile.h"
+#include "sph_walk.h"
 
 static_assert(sizeof(SphParticle) == 80, "SPHParticle must be 80 bytes (SPHFluid3D.h:12-24)");
 
@@ -137,9 +136,6 @@ struct SphEngine {
     std::vector<float> terrainHeights;      // CPU copy of the heightfield (:175); empty = river step off (:512)
     float* d_terrain = nullptr;             // terrainSSBO (binding 7 of TerrainConstraints.comp)
     size_t terrainCap = 0;
-    uint8_t* d_tileDone = nullptr;          // k_sph_tile: 1 = this block of cells was done by it (k_sph_walk takes the others)
-    uint32_t* d_nFallback = nullptr;        // blocks of cells left to k_sph_walk in this substep (zeroed by the scan)
-    int tileCap = 0;
     float4 *d_sPV = nullptr, *d_sOwn = nullptr;   // sorted copy of the entry state: 32-byte records (pos, 1/rho | vel, P) + own data
     size_t sortedCap = 0;
     float4* d_shapeTab = nullptr;           // sampled curve of container shapes 9/11/12/14 (128 points)
@@ -239,7 +235,6 @@ void free_grid_buffers(SphEngine* e) {
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);   // captured launches hold these addresses
     e->graphs.clear();
     dev_free(e->d_cellCount); dev_free(e->d_cellStart); dev_free(e->d_blockSums);
-    dev_free(e->d_tileDone); dev_free(e->d_nFallback); e->tileCap = 0;
     e->allocatedCells = 0;
 }
 
@@ -278,8 +273,6 @@ int ensure_grid_buffers(SphEngine* e) {
     if ((rc = dev_alloc(&e->d_cellCount, C))) return rc;
     if ((rc = dev_alloc(&e->d_cellStart, C + 1))) return rc;
     if ((rc = dev_alloc(&e->d_blockSums, (size_t)blocks_for(C, kScanTile) + 1))) return rc;
-    if ((rc = dev_alloc(&e->d_tileDone, C)) || (rc = dev_alloc(&e->d_nFallback, (size_t)1))) return rc;   // (one flag per block of cells: <= C)
-    HIP_TRY(hipMemsetAsync(e->d_nFallback, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(hipMemsetAsync(e->d_cellCount, 0, C * sizeof(uint32_t), e->stream));
     e->allocatedCells = want;
     return SPH_OK;
@@ -347,7 +340,7 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     {
         Timed t(e, SPH_K_SCAN);
         const int rawSums = sb <= kScanFusedBlocks ? 1 : 0;
-        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, C, e->d_nFallback);
+        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, C);
         if (!rawSums) hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kBlock), 0, e->stream, e->d_blockSums, sb);
         hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(kBlock), 0, e->stream, e->d_cellCount, e->d_blockSums, e->d_cellStart, C, (uint32_t)n, rawSums);
     }
@@ -454,17 +447,7 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             hipLaunchKernelGGL(k_sph_ll, dim3(blocks_for(n)), dim3(kBlock), 0, e->stream, k, in, out, cellHead, e->d_llNext, n);
         }
     } else {
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3        // timing experiment only: substeps that reuse the kept lists also skip the grid build (frozen order)
-    if (!(e->debugFlags & 32))
-#endif
     if ((rc = build_grid(e, k, true))) return rc;                           // :449-468
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
-    static uint16_t* expLists = nullptr;
-    if (!expLists) { const size_t per = (size_t)SPH_WALK_MAXN * 256 + 2 * 256 + 2 * 4 * 16; if ((rc = dev_alloc(&expLists, per * (size_t)(8 * ((blocks_for(n, 256) + 7) / 8))))) return rc; }
-#define EXP_LISTS_ARG , expLists
-#else
-#define EXP_LISTS_ARG
-#endif
     if (n) {                                                                // :470-509 (SPH + OBB fused)
         if (!e->d_sPV || e->sortedCap < (size_t)n) return fail(SPH_ERR_STATE, "sorted copy missing");
         const uint32_t* live = e->slab ? e->d_cellStart + k.numCells : nullptr;
@@ -472,31 +455,14 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
         Timed t(e, SPH_K_SPH);
         if (e->optNeighbor >= 3 && (size_t)n < ((size_t)1 << 27)) {        // (buffer loads address the sorted copy with 32-bit byte offsets)
             const dim3 grid(8 * ((blocks_for(n, 256) + 7) / 8));
-            // k_sph_tile first (single-domain engines): one workgroup per block of cells; k_sph_walk behind it takes what it left
-            const bool tiled = e->optNeighbor == 4 && !e->slab;
-            const TileGeom tg{(k.gx + SPH_TILE_X - 1) / SPH_TILE_X, (k.gy + SPH_TILE_Y - 1) / SPH_TILE_Y, (k.gz + SPH_TILE_Z - 1) / SPH_TILE_Z};
-            const uint8_t* behind = nullptr;
-            if (tiled) {
-                const int nTiles = tg.ntx * tg.nty * tg.ntz;
-                const dim3 tgrid(8 * ((nTiles + 7) / 8));
-                if (k.h2 <= 1.0f)
-                    hipLaunchKernelGGL((k_sph_tile<SPH_TILE_X, SPH_TILE_Y, SPH_TILE_Z, SPH_TILE_WAVES, SPH_TILE_CAP, SPH_TILE_MAXN, SPH_TILE_UNROLL, true>), tgrid,
-                                       dim3(SPH_TILE_WAVES * 64), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, tg, e->d_tileDone, e->d_nFallback,
-                                       e->debugFlags, e->d_stats);
-                else
-                    hipLaunchKernelGGL((k_sph_tile<SPH_TILE_X, SPH_TILE_Y, SPH_TILE_Z, SPH_TILE_WAVES, SPH_TILE_CAP, SPH_TILE_MAXN, SPH_TILE_UNROLL, false>), tgrid,
-                                       dim3(SPH_TILE_WAVES * 64), 0, e->stream, k, S, in, out, e->d_order, e->d_cellStart, tg, e->d_tileDone, e->d_nFallback,
-                                       e->debugFlags, e->d_stats);
-                behind = e->d_tileDone;
-            }
             auto walk = [&](hipStream_t st, const uint32_t* lo, const uint32_t* hi, bool bothEnds = false) {
                 const int dbg = (e->debugFlags & ~256) | (bothEnds ? 256 : 0);    // (bit 8: the launch covers [0, *lo) and [*hi, end) instead of [*lo, *hi))
                 if (k.h2 <= 1.0f)
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, true>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, dbg, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
+                                       e->d_order, e->d_cellStart, live, n, dbg, e->d_stats, lo, hi);
                 else
                     hipLaunchKernelGGL((k_sph_walk<SPH_WALK_MAXN, SPH_WALK_UNROLL, SPH_WALK_CAP, false>), grid, dim3(256), 0, st, k, S, in, out,
-                                       e->d_order, e->d_cellStart, live, n, dbg, e->d_stats, lo, hi, behind, e->d_nFallback, tg EXP_LISTS_ARG);
+                                       e->d_order, e->d_cellStart, live, n, dbg, e->d_stats, lo, hi);
             };
             // The pack of the next exchange only reads the slots of the kSlabDepth lowest / highest local cell layers (k_slab_pack,
             // under the same conditions): those two slot ranges first, the event, then everything in between.
@@ -507,33 +473,15 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
             if (split) {
                 const uint32_t* endLo = e->d_cellStart + kSlabDepth * (size_t)(k.gx * k.gy);
                 const uint32_t* startHi = e->d_cellStart + (size_t)(k.gz - kSlabDepth) * (size_t)(k.gx * k.gy);
-                // The two face ranges are small launches (three layers each); alone in front of the interior each would leave the
-                // machine half empty at its tail.  They stay FIRST on the engine's stream -- the exchange behind them needs them
-                // early: the transfer has to fit beside the interior -- and the interior goes to a LOW-priority stream of its own
-                // that starts behind the FIRST face launch: beside the second one and, later, beside the pack / unpack kernels of the
-                // high-priority exchange stream, it fills whatever they leave free.  (Started together with the first face launch it
-                // takes half the machine from both of them and the exchange begins 410 us into the pass instead of 250: measured,
-                // profiles/r03_slab_face_launch_schedules.txt.)  Same inputs, disjoint output slots; the engine's stream joins the
-                // interior at the end of the pass.
-#ifndef SPH_SLAB_INTERIOR_AFTER
-#define SPH_SLAB_INTERIOR_AFTER 0     // 0: the interior starts with the (first) face launch, 1: after the first of two (beside the second), 2: after the faces (no overlap)
-#endif
-#ifndef SPH_SLAB_MERGED_FACES
-#define SPH_SLAB_MERGED_FACES 1       // 1 (round 4): both face ranges in ONE launch (one tail instead of two); the interior then starts with it (INTERIOR_AFTER 0) or behind it (2).
-                                      // One rank's share of configs[4], bench.py --slab-path, 60 substeps: two launches + interior behind the first 1.351-1.355 ms,
-                                      // merged + interior at once 1.313-1.316, merged + interior behind 1.348-1.354 (profiles/r04_slab_face_launch_schedules.txt)
-#endif
-                if (SPH_SLAB_MERGED_FACES) {
-                    if (SPH_SLAB_INTERIOR_AFTER == 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
-                    walk(e->stream, endLo, startHi, true);
-                    if (SPH_SLAB_INTERIOR_AFTER != 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
-                } else {
-                if (SPH_SLAB_INTERIOR_AFTER == 0) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
-                walk(e->stream, nullptr, endLo);
-                if (SPH_SLAB_INTERIOR_AFTER == 1) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
-                walk(e->stream, startHi, nullptr);
-                if (SPH_SLAB_INTERIOR_AFTER == 2) HIP_TRY(hipEventRecord(e->evSorted, e->stream));
-                }
+                // Both face ranges go FIRST, as ONE launch on the engine's stream (one tail instead of two) -- the exchange behind them needs them
+                // early: the transfer has to fit beside the interior -- and the interior goes to a LOW-priority stream of its own that starts
+                // with the face launch: beside it and, later, beside the pack / unpack kernels of the high-priority exchange stream, it fills
+                // whatever they leave free.  Same inputs, disjoint output slots; the engine's stream joins the interior at the end of the pass.
+                // Measured schedules (one rank's share of configs[4], bench.py --slab-path): this one 1.313-1.316 ms per substep; two face
+                // launches + interior behind the first 1.351-1.355; merged faces + interior behind them 1.348-1.354
+                // (profiles/r03_slab_face_launch_schedules.txt, profiles/r04_slab_face_launch_schedules.txt).
+                HIP_TRY(hipEventRecord(e->evSorted, e->stream));
+                walk(e->stream, endLo, startHi, true);
                 HIP_TRY(hipEventRecord(e->evBoundary, e->stream));
                 HIP_TRY(hipStreamWaitEvent(e->bstream, e->evSorted, 0));
                 walk(e->bstream, endLo, startHi);
@@ -804,7 +752,7 @@ int sph_get_params(const SphEngine* e, SphParams* out) {
 int sph_set_option(SphEngine* e, int option, int value) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     switch (option) {
-    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 4) return fail(SPH_ERR_ARG, "SPH pass %d: 4 = k_sph_tile, 3 = k_sph_walk, 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, was retired)", value); e->optNeighbor = value; break;
+    case SPH_OPT_NEIGHBOR_KERNEL: if (value < 1 || value > 3) return fail(SPH_ERR_ARG, "SPH pass %d: 3 = k_sph_walk, 2 = k_sph_list, 1 = k_sph_slow (0, the round-1 LDS tile pass, and 4, round 4's k_sph_tile, were retired)", value); e->optNeighbor = value; break;
     case SPH_OPT_GRID_BUILD: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optGridBuild = value; break;
     case SPH_OPT_AOS_MODE: if (value < 0 || value > 1) return fail(SPH_ERR_ARG, "bad value"); e->optAos = value; break;
     case SPH_OPT_TIMING: if (value < 0 || value > 2) return fail(SPH_ERR_ARG, "bad value"); e->optTiming = value; break;

@@ -121,9 +121,8 @@ __device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, in
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ blockSums, int numCells, uint32_t* __restrict__ zeroMe) {
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ blockSums, int numCells) {
     __shared__ uint32_t sm[4];
-    if (zeroMe && blockIdx.x == 0 && threadIdx.x == 0) *zeroMe = 0u;   // k_sph_tile's count of blocks of cells left to k_sph_walk (per substep)
     const int c0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
     scan_load16(cnt, c0, numCells, v);

@@ -32,37 +32,11 @@ namespace sph {
 #ifndef SPH_WALK_WAVES
 #define SPH_WALK_WAVES 5     // __launch_bounds__ minimum waves per SIMD
 #endif
-#ifndef SPH_WALK_REORDER
-#define SPH_WALK_REORDER 0   // 1: after sweep 1 the block's targets are handed to the lanes in order of their list length (round 4 experiment, bit-exact,
-                             // NOT faster: 446 -> 515 us, profiles/r04_walk_reorder_experiment.txt: a wave of scattered targets gathers from 4x the cache lines)
-#endif
-#ifndef SPH_WALK_PACKED
-#define SPH_WALK_PACKED 0    // 1: sweep 1 takes two staged candidates per step out of structure-of-arrays windows, the distance and the list test as v_pk_*_f32 (round 4 experiment, section 11.2)
-#endif
-#ifndef SPH_WALK_STAGE_RSRC
-#define SPH_WALK_STAGE_RSRC 1  // 1 (round 4): the windows' loads as bounds-checked buffer loads over a per-row resource [A, B): no per-lane clamp, no 64-bit address arithmetic
-                               // (443-445 us against 447-449 with clamped global loads, gpurun_out/abw_rs.log -> profiles/r04_walk_stage_rsrc.txt)
-#endif
 #ifndef SPH_WALK_EPS
 #define SPH_WALK_EPS 0.04f   // slack of the list around the predicted position, in units of h (0.03 / 0.04 / 0.06 / 0.08: 442 / 441 / 451 / 463 us)
 #endif
 
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-
-// Blocks of cells of k_sph_tile (sph_tile.h).  k_sph_walk runs behind it for the blocks it could not take (tileDone[block] == 0).
-#ifndef SPH_TILE_X
-#define SPH_TILE_X 8
-#endif
-#ifndef SPH_TILE_Y
-#define SPH_TILE_Y 4
-#endif
-#ifndef SPH_TILE_Z
-#define SPH_TILE_Z 4
-#endif
-struct TileGeom { int ntx, nty, ntz; };   // blocks of cells per axis
-__host__ __device__ __forceinline__ int tile_of_cell(int cx, int cy, int cz, const TileGeom& g) {
-    return ((cz / SPH_TILE_Z) * g.nty + cy / SPH_TILE_Y) * g.ntx + cx / SPH_TILE_X;
-}
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byteOff) {
     const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteOff, 0, 0);   // out of range reads return 0, never fault
@@ -107,12 +81,7 @@ template <int MAXN, int UNROLL, int CAP, bool SMALLH>
 __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, SortedIn S, StateIn in, StateOut out, const uint32_t* __restrict__ order,
                                                                   const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ liveCount, int n,
                                                                   int dbg, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ rangeLo,
-                                                                  const uint32_t* __restrict__ rangeHi, const uint8_t* __restrict__ tileDone,
-                                                                  const uint32_t* __restrict__ nFallback, TileGeom tg
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3        // timing experiment only (tools/list_reuse_bound.py): the lists of one substep kept in global memory
-                                                                  , uint16_t* __restrict__ expLists
-#endif
-                                                                  ) {
+                                                                  const uint32_t* __restrict__ rangeHi) {
     constexpr int kB = 256;
     constexpr uint32_t kRowBytes = kB * 2;                 // one list row = one entry of every thread
     static_assert(kRowBytes == 512, "the cursor advance reads bit 9 of (sign >> 22)");
@@ -123,7 +92,6 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     static_assert(CAP <= 192, "the window is staged with three loads per lane, and a window offset has 8 bits in an entry");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    if (tileDone && *nFallback == 0u) return;              // behind k_sph_tile: it took every block of cells
     // XCD-aware block mapping as in k_sph_list: blocks b and b + 8 share an XCD, each XCD walks one contiguous eighth of the LIVE slots.
     // A launch may cover only the slot range [*rangeLo, *rangeHi) (device-side bounds, nullptr = open end): a z-slab engine
     // runs the slots next to its faces first, so that the halo exchange can start while the interior is still being computed.
@@ -154,9 +122,6 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     o.px = P.x; o.py = P.y; o.pz = P.z; o.vx = V.x; o.vy = V.y; o.vz = V.z; o.rho = 0.0f; o.prs = 0.0f;
     const uint32_t cb = fbits(O.x);
     const int cx = (int)(cb & 1023u), cy = (int)((cb >> 10) & 1023u), cz = (int)(cb >> 20);
-    if (tileDone) {                                        // targets of a block of cells that k_sph_tile has done
-        if (live && tileDone[tile_of_cell(cx, cy, cz, tg)]) live = false;
-    }
     const int xlo = max(cx - 1, 0), xhi = min(cx + 1, k.gx - 1);
     const __amdgpu_buffer_rsrc_t bufPV = __builtin_amdgcn_make_buffer_rsrc((void*)S.pv, 0, (int)((uint32_t)n * 32u), 0x00020000);
     // The list must hold every candidate within h of the ENTRY position (sweep 2) and of the position after this substep's
@@ -222,56 +187,29 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)q1, ll);
         aN = A; bN = B;
         stagedN = (B - A) <= (uint32_t)CAP && !(dbg & 4);  // wave-uniform
-#if SPH_WALK_STAGE_RSRC
         if (stagedN) {                                     // the window's loads through a buffer resource over exactly [A, B): no per-lane clamp or 64-bit address, a load past B returns 0 (never read)
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(S.pv + 2u * (size_t)A), 0, (int)((B - A) * 32u), 0x00020000);
             pre0 = buf_load4(rw, laneOff32);
             if (CAP > 64) pre1 = buf_load4(rw, laneOff32 + 2048u);
             if (CAP > 128) pre2 = buf_load4(rw, laneOff32 + 4096u);
         }
-#else
-        if (stagedN) {                                     // clamped, unconditional: B - A >= 1 here
-            pre0 = S.P(A + min((uint32_t)lane, B - A - 1u));
-            if (CAP > 64) pre1 = S.P(A + min((uint32_t)lane + 64u, B - A - 1u));
-            if (CAP > 128) pre2 = S.P(A + min((uint32_t)lane + 128u, B - A - 1u));
-        }
-#endif
     };
     int nRows = 0, nUnstaged = 0;
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
-    uint16_t* const expBase = expLists + (size_t)vb * (size_t)(MAXN * kB + 2 * kB + 2 * (kB / 64) * 16);
-    const bool expReuse = (dbg & 32) != 0;
-    if (!expReuse) plan(qs[0], qe[0]);
-#pragma unroll
-    for (int r = 0; r < (expReuse ? 0 : 9); ++r) {
-#else
     plan(qs[0], qe[0]);
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-#endif
         const uint32_t q0 = qs[r], q1 = qe[r];
         const bool ne = q1 > q0;
         const unsigned long long mne = mneN;
         const uint32_t A = aN, B = bN;
         const bool staged = stagedN;
         const bool selfRow = (r == 4);
-#if SPH_WALK_PACKED
-        float* const wx = reinterpret_cast<float*>(&stage[wv][0]);           // the window as three arrays: two consecutive candidates' x (y, z) sit side by side
-        float* const wy = wx + CAP;
-        float* const wz = wy + CAP;
-        if (mne != 0ull && staged) {
-            wx[lane] = pre0.x; wy[lane] = pre0.y; wz[lane] = pre0.z;
-            if (CAP > 64 && (CAP >= 128 || lane < CAP - 64)) { wx[lane + 64] = pre1.x; wy[lane + 64] = pre1.y; wz[lane + 64] = pre1.z; }
-            if (CAP > 128 && lane < CAP - 128) { wx[lane + 128] = pre2.x; wy[lane + 128] = pre2.y; wz[lane + 128] = pre2.z; }
-        }
-#else
         if (mne != 0ull && staged) {                       // this row's window into LDS (lanes past the union store duplicates)
             const uint32_t e0 = ((uint32_t)r << 12) | ((uint32_t)lane << 4);
             stage[wv][lane] = make_float4(pre0.x, pre0.y, pre0.z, bitsf(e0));
             if (CAP > 64 && (CAP >= 128 || lane < CAP - 64)) stage[wv][lane + 64] = make_float4(pre1.x, pre1.y, pre1.z, bitsf(e0 + (64u << 4)));
             if (CAP > 128 && lane < CAP - 128) stage[wv][lane + 128] = make_float4(pre2.x, pre2.y, pre2.z, bitsf(e0 + (128u << 4)));
         }
-#endif
         if (r < 8) plan(qs[r + 1], qe[r + 1]);
         if (mne == 0ull) continue;
         nRows += 1; nUnstaged += staged ? 0 : 1;           // (wave-uniform; diagnostics only)
@@ -280,42 +218,6 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         if (B - A > 255u) listOk = false;                  // offsets beyond the entry format (wave-uniform)
         const uint32_t off = ne ? q0 - A : 0u;
         if (selfRow) eSelf = (4u << 12) | ((((uint32_t)s - A) << 4) & 0xff0u);
-#if SPH_WALK_PACKED
-        if (staged) {
-            __builtin_amdgcn_wave_barrier();
-            const float* __restrict__ px = wx + off;
-            const float* __restrict__ py = wy + off;
-            const float* __restrict__ pz = wz + off;
-            uint32_t e = ((uint32_t)r << 12) | (off << 4);
-            uint32_t m = 0;
-            for (; m + 2u <= len; m += 2u, e += 32u) {
-                const v2f X = {px[m], px[m + 1u]}, Y = {py[m], py[m + 1u]}, Z = {pz[m], pz[m + 1u]};
-                cur = min(cur, curEnd);
-                // two candidates: the same operations as visit(), each half of a packed instruction rounds like the scalar one; the density sum and the list stay sequential
-                const v2f dx = o.px - X, dy = o.py - Y, dz = o.pz - Z;
-                const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                const v2f hm = k.h2 - r2;
-                const v2f t = {SMALLH ? __builtin_amdgcn_fmed3f(hm.x, 0.0f, 1.0f) : fmaxf(hm.x, 0.0f), SMALLH ? __builtin_amdgcn_fmed3f(hm.y, 0.0f, 1.0f) : fmaxf(hm.y, 0.0f)};
-                const v2f tt = t * t;
-                o.dsum = fmaf(tt.x, t.x, o.dsum);
-                o.dsum = fmaf(tt.y, t.y, o.dsum);
-                const v2f ez2 = {ez, ez}, ey2 = {ey, ey}, ex2 = {ex, ex}, nb2 = {-kBig, -kBig};
-                const v2f w = __builtin_elementwise_fma(ez2, dz, __builtin_elementwise_fma(ey2, dy, __builtin_elementwise_fma(ex2, dx, r2 + c0)));
-                v2f sg = __builtin_elementwise_fma(nb2, t, w);
-                if (selfRow) { sg.x = (e == eSelf) ? 1.0f : sg.x; sg.y = (e + 16u == eSelf) ? 1.0f : sg.y; }
-                *reinterpret_cast<uint16_t*>(nlBytes + cur) = (uint16_t)e;
-                cur += (fbits(sg.x) >> 22) & adv;
-                *reinterpret_cast<uint16_t*>(nlBytes + cur) = (uint16_t)(e + 16u);
-                cur += (fbits(sg.y) >> 22) & adv;
-            }
-            if (m < len) {
-                const float4 J = make_float4(px[m], py[m], pz[m], 0.0f);
-                cur = min(cur, curEnd);
-                visit(J, e, selfRow);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else
-#endif
         if (staged) {
             __builtin_amdgcn_wave_barrier();
             const float4* __restrict__ wp = &stage[wv][off];
@@ -354,118 +256,23 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
         }
     }
     __builtin_amdgcn_wave_barrier();                       // rowA written by lane 0, read by every lane below
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
-    {
-        uint32_t* const gCur = reinterpret_cast<uint32_t*>(expBase + MAXN * kB);
-        uint32_t* const gRowA = gCur + kB;
-        if (dbg & 64) {                                    // keep this substep's lists
-            for (int e = 0; e < MAXN; ++e) expBase[e * kB + tid] = nl[e][tid];
-            gCur[tid] = cur;
-            if (lane < 16) gRowA[wv * 16 + lane] = rowA[wv][lane];
-        }
-        if (expReuse) {                                    // sweep 1 = the kept lists (coalesced reads), then a walk for the density
-            cur = live ? gCur[tid] : (uint32_t)tid * 2u;
-            if (lane < 16) rowA[wv][lane] = gRowA[wv * 16 + lane];
-            const uint32_t rows = (cur - (uint32_t)tid * 2u) / kRowBytes;
-            uint32_t maxRows = rows;
-            for (int d = 32; d >= 1; d >>= 1) maxRows = max(maxRows, (uint32_t)__shfl_xor((int)maxRows, d, 64));
-            for (uint32_t e = 0; e < maxRows; ++e) nl[e][tid] = expBase[e * kB + tid];
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-#endif
     listOk = (listOk && cur < curEnd) || !live;            // a cursor that reached the end may have dropped entries; lanes without a target never fall back
     finish_density(k, o);
 
-#if SPH_WALK_REORDER
-    // ---- hand the block's 256 targets to the lanes in the order of their list length (round 4) ----
-    // The walks below are per-lane loops: a wave runs to its longest list, and the lists of 64 consecutive targets differ by
-    // +- 2.5 entries around 10 (16 slots for 10.1 entries).  A counting sort over the block by list length (targets without a usable
-    // list last, lanes without a target first) makes the lists of a wave equal to within an entry or two.  Which lane computes a
-    // target changes nothing in its arithmetic.  The windows of sweep 1 are dead by now: their LDS holds the sort's scratch.
-    static_assert(sizeof(float4) * (kB / 64) * CAP >= kB * 16 + 64 * 4, "the sort's scratch lives in the windows");
-    uint32_t* const sHist = reinterpret_cast<uint32_t*>(&stage[0][0]);                // [64] bins: list length (0 .. MAXN), MAXN + 1 = no usable list
-    float2* const sRP = reinterpret_cast<float2*>(sHist + 64);                      // [kB] density / pressure of this substep
-    uint32_t* const sCur = reinterpret_cast<uint32_t*>(sRP + kB);                   // [kB] list end | live << 30 | listOk << 31
-    uint16_t* const sPerm = reinterpret_cast<uint16_t*>(sCur + kB);                 // [kB] target (old thread index) of each lane
-    __syncthreads();                                       // every wave is through its windows
-    if (tid < 64) sHist[tid] = 0u;
-    __syncthreads();
-    const uint32_t key = !live ? 0u : (listOk ? 1u + (cur - (uint32_t)tid * 2u) / kRowBytes : (uint32_t)MAXN + 2u);
-    static_assert(MAXN + 3 <= 64, "bins");
-    const uint32_t inBin = atomicAdd(&sHist[key], 1u);
-    sRP[tid] = make_float2(o.rho, o.prs);
-    sCur[tid] = cur | (live ? 1u << 30 : 0u) | (listOk ? 1u << 31 : 0u);
-    __syncthreads();
-    if (wv == 0) {
-        const uint32_t c = sHist[lane];
-        const uint32_t inc = wave_incl_scan(c);
-        sHist[lane] = inc - c;
-    }
-    __syncthreads();
-    sPerm[sHist[key] + inBin] = (uint16_t)tid;
-    __syncthreads();
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 2        // timing experiment only: all the machinery, but every lane keeps its target
-    const int me = ((int)sPerm[tid] & 0) | tid;
-#else
-    const int me = (int)sPerm[tid];
-#endif                        // this lane's target from here on: the one thread `me` took through sweep 1
-    const uint32_t cw = sCur[me];
-    live = (cw >> 30) & 1u;
-    listOk = (cw >> 31) != 0u;
-    cur = cw & 0x3fffffffu;
-    const int sN = live ? first + vb * kB + me : max(bound - 1, 0);
-    const float4 PN = S.P(sN), VN = S.V(sN), ON = S.own[sN];
-    const float2 rpN = sRP[me];
-    own_reset(o);
-    o.px = PN.x; o.py = PN.y; o.pz = PN.z; o.vx = VN.x; o.vy = VN.y; o.vz = VN.z; o.rho = rpN.x; o.prs = rpN.y;
-    const uint32_t cbN = fbits(ON.x);
-    const int cxN = (int)(cbN & 1023u), cyN = (int)((cbN >> 10) & 1023u), czN = (int)(cbN >> 20);
-    const int xloN = max(cxN - 1, 0), xhiN = min(cxN + 1, k.gx - 1);
-    const float qxN = fmaf(0.995f * fmaf(k.gravx, k.dt, o.vx), k.dt, o.px), qyN = fmaf(0.995f * fmaf(k.gravy, k.dt, o.vy), k.dt, o.py),
-                qzN = fmaf(0.995f * fmaf(k.gravz, k.dt, o.vz), k.dt, o.pz);
-#define W_S sN
-#define W_O ON
-#define W_CX cxN
-#define W_CY cyN
-#define W_CZ czN
-#define W_XLO xloN
-#define W_XHI xhiN
-#define W_QX qxN
-#define W_QY qyN
-#define W_QZ qzN
-#define W_ME me
-#else
-#define W_S s
-#define W_O O
-#define W_CX cx
-#define W_CY cy
-#define W_CZ cz
-#define W_XLO xlo
-#define W_XHI xhi
-#define W_QX qx
-#define W_QY qy
-#define W_QZ qz
-#define W_ME tid
-#endif
 
     // ---- walks of sweeps 2 / 3: per-lane loops over the list; the 32-byte records of the next two entries are in flight ----
-    const char* const rowBytes = reinterpret_cast<const char*>(&rowA[W_ME >> 6][0]);
+    const char* const rowBytes = reinterpret_cast<const char*>(&rowA[tid >> 6][0]);
     auto fetch = [&](uint32_t at, float4& J, float4& JV) {
         const uint32_t ent = *reinterpret_cast<const uint16_t*>(nlBytes + at);
         const uint32_t base = *reinterpret_cast<const uint32_t*>(rowBytes + ((ent >> 10) & 0x3cu));
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 1       // timing experiment only: every lane gathers record 0 (same instructions, no cache-line traffic)
-        const uint32_t qb = (base + ((ent & 0xff0u) << 1)) & 0u;
-#else
         const uint32_t qb = base + ((ent & 0xff0u) << 1);
-#endif
         J = buf_load4(bufPV, qb); JV = buf_load4(bufPV, qb + 16u);   // (a stale entry past the list gives any offset: bounds-checked, unused)
     };
     auto listed = [&](auto&& f) {
         // The pass is bound by the cache lines its gathers touch in L1 (profiles/r03_walk_mem_counters.log: ~0.9 tag lookups per
         // cycle and CU), so a look-ahead load is issued only for an entry that exists: no lane ever fetches past its list.
         const uint32_t end = cur;                          // <= curEnd - kRowBytes here
-        uint32_t at = (uint32_t)W_ME * 2u;
+        uint32_t at = (uint32_t)tid * 2u;
         float4 J0, V0, J1, V1, J2, V2, J3, V3;
         J0 = V0 = J1 = V1 = J2 = V2 = J3 = V3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (at < end) fetch(at, J0, V0);
@@ -488,74 +295,42 @@ __global__ __launch_bounds__(256, SPH_WALK_WAVES) void k_sph_walk(SimK k, Sorted
     // Exact fallback of a sweep for lanes whose list cannot be used: every candidate again, in canonical order, from global memory.
     auto plain = [&](auto&& f) {
         for (int r = 0; r < 9; ++r) {
-            const int nz = W_CZ + r / 3 - 1, ny = W_CY + r % 3 - 1;
+            const int nz = cz + r / 3 - 1, ny = cy + r % 3 - 1;
             if (nz < 0 || nz >= k.gz || ny < 0 || ny >= k.gy) continue;
             const int rowBase = (nz * k.gy + ny) * k.gx;
-            const uint32_t a = cellStart[rowBase + W_XLO], b = cellStart[rowBase + W_XHI + 1];
+            const uint32_t a = cellStart[rowBase + xlo], b = cellStart[rowBase + xhi + 1];
             // (a candidate outside h of every lane that is here adds +-0 everywhere: the wave skips its pair arithmetic)
             auto within = [&](const float4& J) { const float dx = o.px - J.x, dy = o.py - J.y, dz = o.pz - J.z; return dot3(dx, dy, dz, dx, dy, dz) < k.h2; };
             uint32_t q = a;
             for (; q + 2u <= b; q += 2u) {                    // two candidates' loads in flight (in compressed fluid they are broadcasts: the wave's targets share their candidates)
                 const float4 J0 = S.P(q), V0 = S.V(q), J1 = S.P(q + 1u), V1 = S.V(q + 1u);
-                if (__any(within(J0))) f(J0, V0, (int32_t)((int)q != W_S ? -1 : 0));
-                if (__any(within(J1))) f(J1, V1, (int32_t)((int)(q + 1u) != W_S ? -1 : 0));
+                if (__any(within(J0))) f(J0, V0, (int32_t)((int)q != s ? -1 : 0));
+                if (__any(within(J1))) f(J1, V1, (int32_t)((int)(q + 1u) != s ? -1 : 0));
             }
-            if (q < b) { const float4 J = S.P(q); if (__any(within(J))) f(J, S.V(q), (int32_t)((int)q != W_S ? -1 : 0)); }
+            if (q < b) { const float4 J = S.P(q); if (__any(within(J))) f(J, S.V(q), (int32_t)((int)q != s ? -1 : 0)); }
         }
     };
     auto force_at = [&](const float4& J, const float4& JV) { pair_force_other(k, o, J, JV); };
     auto xsph_at = [&](const float4& J, const float4& JV) { pair_xsph_other<SMALLH>(k, o, J, JV); };
     auto force_plain = [&](const float4& J, const float4& JV, int32_t ok) { pair_force(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, JV.w, J.w, ok); };
     auto xsph_plain = [&](const float4& J, const float4& JV, int32_t ok) { pair_xsph(k, o, J.x, J.y, J.z, JV.x, JV.y, JV.z, J.w, ok); };
-#if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 1   // timing experiment only: stop after sweep 1
-    if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, (float)cur, o.ay, o.az, o.rho, o.prs, W_O.y, W_CZ);
-    return;
-#endif
-#if defined(SPH_WALK_EXP) && SPH_WALK_EXP == 3
-    if (expReuse) {                                        // the density from the kept list (one 16-byte gather per entry) + the target itself
-        auto density_at = [&](const float4& J, const float4&) {
-            const float dx = o.px - J.x, dy = o.py - J.y, dz = o.pz - J.z;
-            const float r2 = dot3(dx, dy, dz, dx, dy, dz);
-            const float t = SMALLH ? __builtin_amdgcn_fmed3f(k.h2 - r2, 0.0f, 1.0f) : fmaxf(k.h2 - r2, 0.0f);
-            o.dsum = fmaf(t * t, t, o.dsum);
-        };
-        listed(density_at);
-        o.dsum = fmaf(k.h2 * k.h2, k.h2, o.dsum);
-        finish_density(k, o);
-    }
-#endif
     // ---- sweep 2 ----
     if (listOk) listed(force_at); else plain(force_plain);
     integrate(k, o);
-#if defined(SPH_WALK_CUT) && SPH_WALK_CUT == 2   // timing experiment only: stop after sweep 2
-    if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, W_O.y, W_CZ);
-    return;
-#endif
     // ---- sweep 3: the list stays a superset only while the displacement is inside its slack ----
-    const float mx = o.px - W_QX, my = o.py - W_QY, mz = o.pz - W_QZ;
+    const float mx = o.px - qx, my = o.py - qy, mz = o.pz - qz;
     const float lim = 0.98f * eps;
     const bool near = (dot3(mx, my, mz, mx, my, mz) <= lim * lim && !(dbg & 2)) || !live;
     if (listOk && near) listed(xsph_at); else plain(xsph_plain);
-    const float foamOut = finish_particle(k, o, W_O.y);
-    if (live) store_fields(k, out, W_S, fbits(W_O.z), fbits(W_O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, W_CZ);
+    const float foamOut = finish_particle(k, o, O.y);
+    if (live) store_fields(k, out, s, fbits(O.z), fbits(O.w), o.px, o.py, o.pz, o.vx, o.vy, o.vz, o.ax, o.ay, o.az, o.rho, o.prs, foamOut, cz);
     if (dbg & 8) {   // diagnostics: [0] candidate rows walked from global memory (window too large), [3] candidate rows, [1] targets on an exact fallback sweep, [2] list entries, [4] lanes, [5] overflowed lists, [6] far targets, [7] waves with a fallback
         const unsigned long long slowT = (unsigned long long)__popcll(__ballot(live && !(listOk && near)));
-        unsigned long long ents = (unsigned long long)((live && listOk) ? (cur - (uint32_t)W_ME * 2u) / kRowBytes : 0u);
+        unsigned long long ents = (unsigned long long)((live && listOk) ? (cur - (uint32_t)tid * 2u) / kRowBytes : 0u);
         for (int d = 32; d >= 1; d >>= 1) ents += (unsigned long long)__shfl_xor((int)ents, d, 64);
         const unsigned long long ovf = (unsigned long long)__popcll(__ballot(live && !listOk)), far = (unsigned long long)__popcll(__ballot(live && listOk && !near));
         if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)nUnstaged); atomicAdd(&stats[3], (unsigned long long)nRows); atomicAdd(&stats[1], slowT); atomicAdd(&stats[2], ents & 0xffffffffull); atomicAdd(&stats[4], 64ull); atomicAdd(&stats[5], ovf); atomicAdd(&stats[6], far); atomicAdd(&stats[7], slowT ? 1ull : 0ull); }
     }
 }
-#undef W_S
-#undef W_O
-#undef W_CX
-#undef W_CY
-#undef W_CZ
-#undef W_XLO
-#undef W_XHI
-#undef W_QX
-#undef W_QY
-#undef W_QZ
-#undef W_ME
 
 }  // namespace sph

@@ -123,7 +123,7 @@ typedef struct SphEngine SphEngine; /* opaque; owns every device buffer (as SPHF
 
 /* ---- engine options (sph_set_option) ------------------------------------------- */
 enum {
-    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 4 = k_sph_tile (round 4, A/B: one workgroup per block of 8 x 4 x 4 cells, the block's hull staged once into LDS, all three sweeps out of LDS; blocks that do not fit go to k_sph_walk; single-domain engines only, a z-slab engine runs k_sph_walk), 3 = k_sph_walk (default: one target per lane, LDS-staged candidate rows, neighbour lists walked per lane over 32-byte records), 2 = k_sph_list (round 2's form of the same plan), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) is refused */
+    SPH_OPT_NEIGHBOR_KERNEL = 1, /* SPH pass: 3 = k_sph_walk (default: one target per lane, LDS-staged candidate rows, neighbour lists walked per lane over 32-byte records), 2 = k_sph_list (round 2's form of the same plan), 1 = k_sph_slow (one target per thread, plain sweeps over global memory); same bits. 0 (round 1's tile pass) and 4 (round 4's k_sph_tile: measured slower everywhere, profiles/r04_tile_pass_experiment.txt) were retired and are refused */
     SPH_OPT_GRID_BUILD = 2,      /* 0 = counting sort (default), 1 = atomicExch linked list as BuildGrid.comp (A/B only; neighbour order then arbitrary) */
     SPH_OPT_AOS_MODE = 3,        /* 1 = lazy (default): the substep keeps its state in the engine's own arrays and the 80-byte records are brought up to date by sph_device_particles() / sph_download_particles() / sph_pack_render_buffer(), i.e. once per rendered frame instead of once per substep (the scattered 52-byte update of every record costs about 13 % of the SPH pass); 0 = eager: the SPH pass also updates the records, they are current after every dispatch. Same values either way. */
     SPH_OPT_GRAPH = 5,           /* 1 = sph_dispatch_n replays a hipGraph once the same call (same members, options, substep count) has been seen twice; default 0 */
@@ -132,7 +132,7 @@ enum {
     /* test / tuning hooks */
     SPH_OPT_DEBUG = 100          /* test hooks of k_sph_walk / k_sph_list -- bit 0: treat every neighbour list as overflowed, bit 1: treat every target as
                                     outside the list's slack (sweep-3 fallback), bit 2: treat every window as overflowed (whole wave falls
-                                    back), bit 3: count fallbacks / list entries / staged candidates for sph_debug_counters, bit 4 (16): k_sph_tile leaves every block of cells to k_sph_walk
+                                    back), bit 3: count fallbacks / list entries / staged candidates for sph_debug_counters
                                     (bit 8 is used internally by the z-slab face launch) */
 };
 

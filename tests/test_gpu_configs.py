@@ -59,13 +59,12 @@ def test_config4_16m_256cubed(pkg):
     g = pkg.compute_grid_extents(sp)
     assert tuple(g.dims) == (256, 256, 256)
     outs = []
-    for neighbor in (4, 3, 1):
+    for neighbor in (3, 1):
         f = _engine(pkg, rec, sp, neighbor)
         f.DispatchN(3)
         outs.append(f.download())
         f.close()
-    assert_records_equal(outs[0], outs[1], "k_sph_tile vs k_sph_walk at 16M / 256^3")
-    assert_records_equal(outs[0], outs[2], "k_sph_tile vs k_sph_slow at 16M / 256^3")
+    assert_records_equal(outs[0], outs[1], "k_sph_walk vs k_sph_slow at 16M / 256^3")
     _properties(syn, cfg, outs[0])
     grp = _group(pkg, halo, rec, sp, 4)                   # the 4 x 64-layer decomposition of the config, in one process
     assert [(s.z0, s.z1) for s in grp.sims] == [(0, 64), (64, 128), (128, 192), (192, 256)]
@@ -98,13 +97,12 @@ def test_config5_slab_8m_obb_wave(pkg):
             obj.DispatchCompute()
 
     outs = []
-    for neighbor in (4, 3, 1):
+    for neighbor in (3, 1):
         f = _engine(pkg, rec, sp, neighbor)
         run(f)
         outs.append(f.download())
         f.close()
-    assert_records_equal(outs[0], outs[1], "k_sph_tile vs k_sph_walk on the configs[4] slab")
-    assert_records_equal(outs[0], outs[2], "k_sph_tile vs k_sph_slow on the configs[4] slab")
+    assert_records_equal(outs[0], outs[1], "k_sph_walk vs k_sph_slow on the configs[4] slab")
     _properties(syn, cfg, outs[0])
     assert np.abs(outs[0]["vel"][:, 1]).max() > 1.0       # the impulses and gravity did act
     grp = _group(pkg, halo, rec, sp, 2)

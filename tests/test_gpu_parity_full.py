@@ -21,7 +21,7 @@ from conftest import assert_records_equal, to_oracle_params
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [("tile", 4), ("walk", 3), ("list", 2)]
+KERNELS = [("walk", 3), ("list", 2)]
 
 
 def _engine(pkg, rec, sp, neighbor):

@@ -227,7 +227,7 @@ def test_oracle_fountain_kat(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("neighbor,aos", [(4, 0), (4, 1), (3, 0), (2, 0), (1, 0), (3, 1)])
+@pytest.mark.parametrize("neighbor,aos", [(3, 0), (2, 0), (1, 0), (3, 1)])
 def test_fountain_matches_oracle(pkg, oracle, neighbor, aos):
     rec, sp = _fountain_scene(pkg)
     f = pkg.SPHFluidGPU.from_particles(rec, sp)

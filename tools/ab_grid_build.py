@@ -15,7 +15,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rec, _ = syn.make_particles(cfg)
 sp = pkg.default_params(**syn.params_fields(cfg))
 out = {"config": cfg.name, "steps": steps}
-for label, build, neighbor in (("counting_sort+k_sph_walk", 0, 3), ("counting_sort+k_sph_tile", 0, 4), ("counting_sort+k_sph_list", 0, 2), ("counting_sort+k_sph_slow", 0, 1),
+for label, build, neighbor in (("counting_sort+k_sph_walk", 0, 3), ("counting_sort+k_sph_list", 0, 2), ("counting_sort+k_sph_slow", 0, 1),
                                ("linked_list+k_sph_ll", 1, 3)):
     sim = pkg.SPHFluidGPU.from_particles(rec, sp)
     sim.set_option(pkg.SPH_OPT_GRID_BUILD, build)

@@ -42,7 +42,7 @@ step = 0
 while step <= last:
     row = {"step": step}
     for kind in kinds:
-        row[{4: "tile", 3: "walk", 2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
+        row[{3: "walk", 2: "list", 1: "slow"}[kind] + "_us"] = timed(kind)
         step += REPS
     print(json.dumps(row), flush=True)
     select(3)
