@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--settled-after", type=int, default=300, help="N = 1: after the timed run, continue the SAME run to this substep and record the settled regime (0 = skip)")
     ap.add_argument("--neighbor", type=int, default=3, choices=(1, 2, 3), help="SPH pass: 3 = k_sph_walk (engine default), 2 = k_sph_list (round 2), 1 = k_sph_slow (plain per-target sweeps)")
     ap.add_argument("--aos", default="lazy", choices=["eager", "lazy"], help="lazy (engine default): the 80-byte records are materialised once per frame; eager: by every substep")
+    ap.add_argument("--deadline", type=float, default=120.0, help="N > 1: seconds a rank waits for its neighbours (handshake of an exchange, drain of its streams) before it prints where it stands and exits 3")
     ap.add_argument("--frame-substeps", type=int, default=16, help="lazy, N = 1: materialise the 80-byte record array (sph_device_particles, what a renderer binds) after every this many "
                     "substeps INSIDE the timed region (Scene0p.h:48 maxSubstepsPerFrame = 16) and once more at its end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,6 +166,8 @@ def main():
         n_local, n_total = len(rec), len(rec)
     else:
         sim = halo.SlabSimulation.from_config(cfg, sp, rank, world, stream=stream, transport="rccl" if backend == "nccl" else "host")
+        if backend == "nccl":
+            sim.engine.set_deadline(args.deadline)     # every wait for a neighbour is bounded: a rank that is stuck says so and exits non-zero
         rec = None
         n_local, n_total = sim.num_owned(), cfg.n
     sim.set_option(pkg.SPH_OPT_NEIGHBOR_KERNEL, args.neighbor)
@@ -172,7 +175,28 @@ def main():
     if args.grid_build == "ll":
         sim.set_option(pkg.SPH_OPT_GRID_BUILD, 1)
 
+    def die(ex, where):
+        """A rank that cannot go on (a neighbour that planned another exchange, or never came: SPH_ERR_STATE / SPH_ERR_TIMEOUT of the handshake or of the
+        deadline-bounded sync) says where it stands and ends -- the process, not just the call: device work is still queued behind a transfer that
+        will never complete, so a normal interpreter exit could wait for ever.  The other ranks run into their own deadline."""
+        plan = None
+        try:
+            p, hs = sim.engine.plan()
+            plan = {"exchange": int(p.exchangeNo), "step": int(p.stepNo), "hold_events": int(p.holdEvents), "send_halo_mig_lo_hi": [int(p.sendHalo[0]), int(p.sendMig[0]), int(p.sendHalo[1]), int(p.sendMig[1])],
+                    "recv_halo_mig_lo_hi": [int(p.recvHalo[0]), int(p.recvMig[0]), int(p.recvHalo[1]), int(p.recvMig[1])], "handshake_wait_ms": round(hs, 3)}
+        except Exception:                                    # noqa: BLE001
+            pass
+        print(json.dumps({"bench_failed": True, "rank": rank, "world": world, "where": where, "substeps_issued": wave["n"], "error": str(ex), "plan": plan}), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    slab_rccl = multi and backend == "nccl"
+
     def barrier():
+        if slab_rccl:                              # never a blind wait: the engine's streams are polled against the deadline first
+            try:
+                sim.engine.sync(deadline=args.deadline)
+            except pkg.SphError as ex:
+                die(ex, "sync")
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -199,17 +223,27 @@ def main():
             sim.ApplyWaveImpulse(1.5, 3.0, wave["phase"], (0.0, 1.0, 0.0))
             wave["phase"] += 4.0 * 16 * 1e-3
         wave["n"] += 1
-        sim.DispatchCompute(dt)
+        try:
+            sim.DispatchCompute(dt)
+        except pkg.SphError as ex:
+            if slab_rccl:
+                die(ex, "substep")
+            raise
         if frame and wave["n"] % frame == 0:
             present()
 
     # N > 1: the transport's health before anything is timed (one grouped ncclSend + ncclRecv of a face-sized message from the rank
     # to itself: the only send / receive a one-GPU box can execute; on a node it still says that RCCL moves bytes on this rank)
     selftest_gbs = None
+    selftest_faces_ms = None
     if multi and backend == "nccl" and isinstance(sim.exchange, halo.RcclComm):
         try:
             sim.exchange.selftest_gbs(1 << 20)
             selftest_gbs = round(sim.exchange.selftest_gbs(int(sim.engine.message_bytes()[2] or sim.engine.message_bytes()[3] or (1 << 24)) & ~3), 1)
+            # ... and the engine's own exchange pattern with the rank as both of its neighbours: the 64-byte plans, then two send / receive pairs of
+            # unequal sizes per neighbour in one group, every byte compared (sph_comm_selftest_faces)
+            fc = int(getattr(sim.engine, "face_cap", 0) or 8192)
+            selftest_faces_ms = round(sim.exchange.selftest_faces(fc, (fc * 3 // 5, fc // 2, fc // 50, fc // 40)), 3)
         except Exception as ex:                              # noqa: BLE001
             print(f"[rank {rank}] RCCL self-test failed: {ex}", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
@@ -317,15 +351,21 @@ def main():
         sim.kernel_times(reset=True)
         sim.set_option(pkg.SPH_OPT_TIMING, 0)
         mb = sim.engine.message_bytes()
-        mine = acc + [float(v) for v in mb]
+        try:
+            hs_ms = sim.engine.plan()[1]
+        except pkg.SphError:
+            hs_ms = 0.0
+        mine = acc + [float(v) for v in mb] + [float(hs_ms)]
         tst = torch.tensor(mine, dtype=torch.float64, device="cuda")
         gathered = [torch.zeros_like(tst) for _ in range(world)]
         dist.all_gather(gathered, tst)
         exchange_diag = {"per_rank": [{"pack_ms": round(g[0].item(), 4), "transfer_ms": round(g[1].item(), 4), "unpack_ms": round(g[2].item(), 4),
                                        "exchange_end_ms": round(g[3].item(), 4), "pass_end_ms": round(g[4].item(), 4),
                                        "hidden_behind_the_pass": bool(g[3].item() <= g[4].item()),
-                                       "sent_bytes_lo_hi": [int(g[5].item()), int(g[6].item())], "face_bytes": int(max(g[7].item(), g[8].item()))} for g in gathered],
-                         "substeps_averaged": nd, "rccl_selftest_gbs": selftest_gbs,
+                                       "sent_bytes_lo_hi": [int(g[5].item()), int(g[6].item())], "face_bytes": int(max(g[7].item(), g[8].item())),
+                                       "handshake_host_wait_ms": round(g[9].item(), 4)} for g in gathered],
+                         "substeps_averaged": nd, "rccl_selftest_gbs": selftest_gbs, "rccl_selftest_faces_ms": selftest_faces_ms,
+                         "verify": "the plans of both ends of every link are compared before a sized message is posted (sph_slab_set_verify 1); handshake_host_wait_ms = host time the last handshake waited for its neighbours",
                          "note": "hipEvents of the last boundary-first steps, untimed for value; halo copies travel as 40-byte records, messages are sized from the counts of two exchanges ago"}
 
     # z-slab runs: overflow of a face buffer or of the slot capacity is flagged on the device, never fatal in the

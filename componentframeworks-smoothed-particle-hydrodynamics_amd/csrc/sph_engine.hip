@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sph_abi.h"
@@ -124,6 +126,19 @@ struct SphEngine {
     uint64_t sentBytes[2] = {0, 0};         // bytes of the last exchange's messages to lo / hi
     int calmHold = 0;                       // exchanges that still send whole faces because something just changed under the fluid (impulse, container, re-prime)
     uint32_t stepNo = 0;                    // boundary-first steps begun
+    // round 5: the PLAN of an exchange and its agreement with the neighbours' plans (slab_plan, slab_intent_mismatch, slab_handshake_rccl)
+    SphSlabIntent intent{};                 // what this engine is about to do in exchange intent.exchangeNo: compared with the neighbours' plans before a sized message is posted
+    bool intentValid = false;
+    uint32_t holdEvents = 0;                // things that set calmHold so far (impulses, container / grid edits, priming exchanges): every rank must have seen the same ones
+    int verifyMode = 1;                     // RCCL transport: 1 (default) = the plans cross each link as a fixed 64-byte message and are compared BEFORE the sized messages are posted
+    double deadlineSec = 30.0;              // host-side limit of a wait for a neighbour (handshake) and of sph_sync_deadline's default
+    float lastDt = 0.0f;                    // dt of the last unpaused dispatch (0: none yet)
+    int tightMessages = 0;                  // test hook (sph_slab_debug_tight_messages): the count of two exchanges ago, no margin, no calm rule
+    hipStream_t hstream = nullptr;          // the handshake's stream
+    hipEvent_t evIntent = nullptr;
+    uint32_t *d_intent = nullptr, *h_intent = nullptr;   // device / pinned host, 48 words: [0..15] this engine's plan, [16..31] the lower neighbour's, [32..47] the upper neighbour's
+    float handshakeMs = 0.0f;               // host time the last handshake waited for its neighbours
+    uint64_t handshakes = 0;
     bool stepPaused = false;                // the pending step is a paused one (nothing was enqueued)
     float packGrid[8] = {0};                // grid (gridMin, cellSize, dims) the halo records in place were cut for
     bool packGridValid = false;
@@ -173,6 +188,12 @@ void container_key(const SphParams& q, float out[15]) {
                          q.param_boxEulerDeg[0], q.param_boxEulerDeg[1], q.param_boxEulerDeg[2], (float)q.param_shapeType,
                          q.param_shapeAux[0], q.param_shapeAux[1], q.param_shapeAux[2], q.param_h, (float)q.grid_cap};
     std::memcpy(out, v, sizeof(v));
+}
+// Something every rank knows to stir the fluid (an impulse, a container / grid edit, a priming exchange): whole faces for three exchanges, and one more
+// event on the count every rank's plan carries (a rank that saw an event its neighbour did not is found by the plans' comparison, not by a hang).
+void slab_hold(SphEngine* e) {
+    e->calmHold = 3;
+    e->holdEvents += 1u;
 }
 bool slab_ranges_usable(const SphEngine* e) {
     if (!e->slabOrderValid) return false;
@@ -406,6 +427,7 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
     int rc;
     if ((rc = validate_params(e->params))) return rc;
     const float dt = overrideDt > 0.0f ? overrideDt : e->params.param_timeStep;   // :434
+    e->lastDt = dt;
     compute_grid_extents(e->params, e->grid);                               // :439
     if ((rc = ensure_grid_buffers(e))) return rc;                           // :440-447
     SimK k;
@@ -554,7 +576,7 @@ int dispatch_one(SphEngine* e, float overrideDt, bool boundaryFirst = false) {
         float cont[15];
         container_key(e->params, cont);
         const bool sameContainer = std::memcmp(cont, e->lastContainer, sizeof(cont)) == 0;
-        if (!sameContainer) e->calmHold = 3;                 // the walls moved under the fluid: whole faces until the counts have been seen calm again
+        if (!sameContainer) slab_hold(e);                    // the walls moved under the fluid: whole faces until the counts have been seen calm again
         std::memcpy(e->lastContainer, cont, sizeof(cont));
         e->slabOrderValid = sorted && sameContainer;
         return SPH_OK;
@@ -583,6 +605,8 @@ int slab_flags_error(const SphEngine* e, uint32_t flags, uint32_t nLo, uint32_t 
     if (flags & 2u) return fail(SPH_ERR_CAPACITY, "slab capacity %zu exceeded while appending halo records", e->cap);
     if (flags & 4u) return fail(SPH_ERR_HIP, "a received halo message did not start with a valid header (magic / count): failed or garbled receive");
     if (flags & 8u) return fail(SPH_ERR_CAPACITY, "a neighbour rank had more halo records than its message could carry (face capacity %u)", e->faceCap);
+    if (flags & 32u) return fail(SPH_ERR_STATE, "the two ends of a link sized an exchange's messages differently (a received header names other message sizes than this engine received): "
+                                                "the ranks' call sequences differ");
     // (flag 16 -- a particle crossed more cell layers in z within one substep than the exchange follows -- loses nothing: it is a notice
     //  that the decomposed run no longer equals the single-domain run, carried by sph_slab_status's out[4], cleared by sph_slab_clear_flags)
     return SPH_OK;
@@ -593,7 +617,7 @@ int launch_impulse(SphEngine* e, const K& kk) {
     int rc;
     if ((rc = import_state(e))) return rc;
     const size_t nw = e->slab ? e->nSlots : e->n;
-    e->calmHold = 3;                                        // (z-slabs: an impulse may set a face's record count moving: whole faces for three exchanges)
+    if (e->slab) slab_hold(e);                              // (z-slabs: an impulse may set a face's record count moving: whole faces for three exchanges)
     if (nw) {
         Timed t(e, SPH_K_IMPULSE);
         hipLaunchKernelGGL((k_impulse<K>), dim3(blocks_for(nw)), dim3(kBlock), 0, e->stream, kk, e->d_pos[e->cur], e->d_vel[e->cur],
@@ -714,6 +738,10 @@ int sph_destroy(SphEngine* e) {
     for (hipEvent_t ev : e->evX) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->evCnt) if (ev) (void)hipEventDestroy(ev);
     if (e->h_cnt) (void)hipHostFree(e->h_cnt);
+    if (e->hstream) { (void)hipStreamSynchronize(e->hstream); (void)hipStreamDestroy(e->hstream); }
+    if (e->evIntent) (void)hipEventDestroy(e->evIntent);
+    if (e->h_intent) (void)hipHostFree(e->h_intent);
+    dev_free(e->d_intent);
     if (e->ownStream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return SPH_OK;
@@ -888,7 +916,8 @@ int sph_apply_wave_impulse(SphEngine* e, float amplitude, float wavelength, floa
     const size_t nw = e->slab ? e->nSlots : e->n;
     // z-slabs: a kick of A changes a particle's step by at most A dt, i.e. a face layer's record count by about A dt / h per substep: a gentle wave (the
     // scene's A = 1.5: 0.5 % of h per substep) leaves a calm face calm; anything that could outgrow the messages' margin within two exchanges holds them whole
-    if (std::fabs(amplitude) * e->params.param_timeStep > 0.02f * e->params.param_h) e->calmHold = 3;
+    // (the dt that is actually stepped: the last dispatch's overrideDt if there was one)
+    if (e->slab && std::fabs(amplitude) * (e->lastDt > 0.0f ? e->lastDt : e->params.param_timeStep) > 0.02f * e->params.param_h) slab_hold(e);
     if (nw) {
         Timed t(e, SPH_K_IMPULSE);
         hipLaunchKernelGGL(k_wave_impulse, dim3(blocks_for(nw)), dim3(kBlock), 0, e->stream, w, e->d_pos[e->cur], e->d_vel[e->cur],
@@ -1295,7 +1324,7 @@ static int slab_pack_on(SphEngine* e, hipStream_t st) {
                            (SlabRec*)e->d_face[0], (SlabRec*)e->d_face[1], e->faceCap, e->faceCap, e->d_slabCnt,
                            slab_ranges_usable(e) ? e->d_cellStart : (const uint32_t*)nullptr, k.gx * k.gy);
         hipLaunchKernelGGL(k_slab_headers2, dim3(1), dim3(1), 0, st, e->d_slabCnt, e->hasLo ? e->d_face[0] : (char*)nullptr,
-                           e->hasHi ? e->d_face[1] : (char*)nullptr, e->faceCap);
+                           e->hasHi ? e->d_face[1] : (char*)nullptr, e->faceCap, e->msgSend[0], e->msgSend[2], e->msgSend[1], e->msgSend[3]);
     }
     HIP_TRY(hipGetLastError());
     return SPH_OK;
@@ -1322,7 +1351,9 @@ static int slab_unpack_on(SphEngine* e, hipStream_t st, const void* recvLo, cons
 }
 int sph_slab_pack_async(SphEngine* e) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
-    e->calmHold = 3;                                        // an exchange outside the sized protocol (priming, re-priming after a grid change): no counts are noted for it
+    if (e->slab) slab_hold(e);                              // an exchange outside the sized protocol (priming, re-priming after a grid change): no counts are noted for it
+    for (int i = 0; i < 4; ++i) e->msgSend[i] = e->msgRecv[i] = e->faceCap;   // whole faces (the headers say so)
+    e->intentValid = false;
     return slab_pack_on(e, e->stream);
 }
 int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, uint32_t recvCap) {
@@ -1335,33 +1366,96 @@ int sph_slab_unpack_async(SphEngine* e, const void* recvLo, const void* recvHi, 
 // within 3 % + 64 records of each other; then it carries the count of e - 2 + a quarter + 1024.  (A face whose count grows faster than that while it
 // was calm two exchanges ago gets cut off: error flag 8 on the receiver, loud.  Random violent scenes showed that a margin alone is not enough:
 // tools/fuzz_sweep.py, 2 of 240 slab runs with the plain "count + 25 % + 1024" rule of the first version.)
-static uint32_t msg_records(uint32_t seen, uint32_t before, uint32_t cap) {
-    static const char* tight = std::getenv("SPH_SLAB_MSG_MARGIN0");          // test hook: the count of two exchanges ago, no margin, no calm test
-    if (tight && tight[0] == '1') return std::min(cap, seen);
+static uint32_t msg_records(uint32_t seen, uint32_t before, uint32_t cap, bool tight = false) {
+    if (tight) return std::min(cap, seen);                                   // test hook (sph_slab_debug_tight_messages): no margin, no calm test
     const uint32_t hi = std::max(seen, before), lo = std::min(seen, before);
     if (hi - lo > hi / 32u + 64u) return cap;                                // not calm: the whole face
     return (uint32_t)std::min<uint64_t>(cap, (uint64_t)seen + seen / 4u + 1024u);
 }
 // host-only: the rule above as a function of (count two exchanges ago, count three exchanges ago, face capacity)
 int sph_slab_message_records(uint32_t seen, uint32_t before, uint32_t cap) { return (int)msg_records(seen, before, cap); }
-static int slab_size_messages(SphEngine* e) {
+
+static uint32_t fnv32(const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 16777619u; }
+    return h;
+}
+constexpr uint32_t kIntentMagic = 0x504c414eu;             // "PLAN"
+// THE PLAN of exchange e->exchangeNo: the records each of this engine's four messages will carry, the records it will post receives for, and the
+// host-side state both derive from (exchange number, hold events, members, pause).  Everything a neighbour must agree with is in these 64 bytes:
+// sph_slab_step_finish_local compares the neighbour ENGINES' plans, the RCCL transport sends the plan across each link as a fixed-size message and
+// compares before a sized message is posted (slab_handshake_rccl).  The one place that reads the counts of two exchanges ago.
+static int slab_plan(SphEngine* e) {
+    // a member that moves the grid or the walls, noticed HERE, before the sizes (sph_slab_exchange sized its messages before anything had
+    // noticed the edit; the pack that follows cuts the records for the NEW grid with a full-slot scan and may fill a face)
+    {
+        SphGridInfo g;
+        sph::compute_grid_extents(e->params, g);
+        float now[8], cont[15];
+        grid_key(g, now);
+        container_key(e->params, cont);
+        const bool gridMoved = e->packGridValid && std::memcmp(now, e->packGrid, sizeof(now)) != 0;
+        const bool wallsMoved = e->lastDt > 0.0f && std::memcmp(cont, e->lastContainer, sizeof(cont)) != 0;   // (before the first dispatch lastContainer is not a container yet)
+        if (gridMoved || wallsMoved) slab_hold(e);
+    }
     for (int i = 0; i < 4; ++i) e->msgSend[i] = e->msgRecv[i] = e->faceCap;
-    const bool hold = e->calmHold > 0;                      // (host-side knowledge, the same on every rank: impulses, container edits and re-priming are collective)
+    const bool hold = e->calmHold > 0;                      // (host-side knowledge that every rank shares IF every rank makes the same calls: the plans' holdEvents say whether they did)
     if (hold) e->calmHold -= 1;
     if (e->exchangeNo >= 3 && !hold) {
         const int s2 = (int)((e->exchangeNo - 2u) & 3u), s3 = (int)((e->exchangeNo - 3u) & 3u);
         if (e->cntValid[s2] && e->cntValid[s3]) {
-            HIP_TRY(hipEventSynchronize(e->evCnt[s2]));     // two exchanges back: long done unless the host is that far ahead of the device
+            HIP_TRY(hipEventSynchronize(e->evCnt[s2]));     // two exchanges back: long done unless the host is that far ahead of the device (the host's look-ahead is bounded by this wait)
             const uint32_t* c = e->h_cnt + 8 * s2;
             const uint32_t* b = e->h_cnt + 8 * s3;
-            for (int i = 0; i < 4; ++i) e->msgSend[i] = msg_records(c[i], b[i], e->faceCap);
-            e->msgRecv[0] = msg_records(c[4], b[4], e->faceCap); e->msgRecv[2] = msg_records(c[5], b[5], e->faceCap);   // from lo: its halo copies, its migrants
-            e->msgRecv[1] = msg_records(c[6], b[6], e->faceCap); e->msgRecv[3] = msg_records(c[7], b[7], e->faceCap);   // from hi
+            const bool tight = e->tightMessages != 0;
+            for (int i = 0; i < 4; ++i) e->msgSend[i] = msg_records(c[i], b[i], e->faceCap, tight);
+            e->msgRecv[0] = msg_records(c[4], b[4], e->faceCap, tight); e->msgRecv[2] = msg_records(c[5], b[5], e->faceCap, tight);   // from lo: its halo copies, its migrants
+            e->msgRecv[1] = msg_records(c[6], b[6], e->faceCap, tight); e->msgRecv[3] = msg_records(c[7], b[7], e->faceCap, tight);   // from hi
         }
     }
     e->sentBytes[0] = e->hasLo ? sizeof(SlabHdr) + (uint64_t)e->msgSend[2] * 64u + (uint64_t)e->msgSend[0] * 40u : 0u;
     e->sentBytes[1] = e->hasHi ? sizeof(SlabHdr) + (uint64_t)e->msgSend[3] * 64u + (uint64_t)e->msgSend[1] * 40u : 0u;
+    SphSlabIntent& I = e->intent;
+    std::memset(&I, 0, sizeof(I));
+    I.magic = kIntentMagic; I.exchangeNo = e->exchangeNo; I.stepNo = e->stepNo; I.faceCap = e->faceCap;
+    for (int d = 0; d < 2; ++d) {
+        const bool has = d ? e->hasHi : e->hasLo;
+        I.sendHalo[d] = has ? e->msgSend[d] : 0u; I.sendMig[d] = has ? e->msgSend[2 + d] : 0u;
+        I.recvHalo[d] = has ? e->msgRecv[d] : 0u; I.recvMig[d] = has ? e->msgRecv[2 + d] : 0u;
+    }
+    I.holdEvents = e->holdEvents;
+    I.paramsHash = fnv32(&e->params, sizeof(e->params));
+    I.flags = (e->params.param_pause ? 1u : 0u) | (e->tightMessages ? 2u : 0u) | (hold ? 4u : 0u);
+    I.zRange = ((uint32_t)e->z0 & 0xffffu) | ((uint32_t)e->z1 << 16);
+    e->intentValid = true;
     return SPH_OK;
+}
+// Does the plan `nb` of the neighbour on side d of `me` (0 = below, 1 = above) fit mine?  On a mismatch `why` says what differs.  Pure host logic: the
+// same function judges a neighbour ENGINE's plan (one process, sph_slab_step_finish_local) and a plan received over RCCL.
+static bool slab_intent_mismatch(const SphSlabIntent& me, const SphSlabIntent& nb, int d, char* why, size_t n) {
+    const int o = 1 - d;                                    // the neighbour's side that faces me
+    const char* side = d ? "upper" : "lower";
+    if (nb.magic != kIntentMagic) { snprintf(why, n, "the %s neighbour sent no plan (magic %08x)", side, nb.magic); return true; }
+    if (nb.exchangeNo != me.exchangeNo) { snprintf(why, n, "the %s neighbour is at exchange %u, this rank at %u (a rank skipped or repeated an exchange)", side, nb.exchangeNo, me.exchangeNo); return true; }
+    if (nb.faceCap != me.faceCap) { snprintf(why, n, "face capacity %u here, %u on the %s neighbour", me.faceCap, nb.faceCap, side); return true; }
+    const uint32_t nz0 = nb.zRange & 0xffffu, nz1 = nb.zRange >> 16, z0 = me.zRange & 0xffffu, z1 = me.zRange >> 16;
+    if (d ? nz0 != z1 : nz1 != z0) { snprintf(why, n, "the %s neighbour owns layers [%u, %u), this rank [%u, %u): not adjacent", side, nz0, nz1, z0, z1); return true; }
+    if (nb.holdEvents != me.holdEvents) {
+        snprintf(why, n, "this rank has seen %u impulses / container edits / priming exchanges, the %s neighbour %u: one of them was issued on one rank only", me.holdEvents, side, nb.holdEvents);
+        return true;
+    }
+    if (nb.paramsHash != me.paramsHash) { snprintf(why, n, "the members (SphParams) differ between this rank and the %s neighbour", side); return true; }
+    if (nb.flags != me.flags) { snprintf(why, n, "pause / hold / message test hook differ (%u here, %u on the %s neighbour)", me.flags, nb.flags, side); return true; }
+    if (nb.sendHalo[o] != me.recvHalo[d] || nb.sendMig[o] != me.recvMig[d]) {
+        snprintf(why, n, "the %s neighbour will send %u halo copies + %u migrants, this rank expects %u + %u", side, nb.sendHalo[o], nb.sendMig[o], me.recvHalo[d], me.recvMig[d]);
+        return true;
+    }
+    if (nb.recvHalo[o] != me.sendHalo[d] || nb.recvMig[o] != me.sendMig[d]) {
+        snprintf(why, n, "this rank will send %u halo copies + %u migrants, the %s neighbour expects %u + %u", me.sendHalo[d], me.sendMig[d], side, nb.recvHalo[o], nb.recvMig[o]);
+        return true;
+    }
+    return false;
 }
 // behind the transfer on `st`: this exchange's true counts (own: slabCnt[12..15]; the neighbours': their headers) on their way to the host
 static int slab_note_counts(SphEngine* e, hipStream_t st) {
@@ -1424,6 +1518,7 @@ int sph_slab_step_begin(SphEngine* e, float overrideDt) {
     if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[0], e->stream));
     e->stepNo += 1u;
     if ((rc = dispatch_one(e, overrideDt, true))) return rc;               // ... -> SPH (faces first, e->evBoundary, interior) on the engine's stream
+    if ((rc = slab_plan(e))) return rc;                                      // the sizes of THIS step's exchange (the pack writes them into the headers)
     HIP_TRY(hipStreamWaitEvent(e->xstream, e->evBoundary, 0));
     for (hipEvent_t ev : e->peerDone)                                        // a neighbour engine of this process may still be copying the last send face
         if (ev) HIP_TRY(hipStreamWaitEvent(e->xstream, ev, 0));
@@ -1454,7 +1549,21 @@ int sph_slab_step_finish_local(SphEngine* e, SphEngine* lo, SphEngine* hi) {
     }
     if (e->stepPaused) { e->stepPending = false; return SPH_OK; }   // (stepPaused keeps saying what this step was: the neighbours compare)
     int rc;
-    if ((rc = slab_size_messages(e))) return rc;
+    // Both ends of a link must have planned the same messages (each derived its sizes on its own: the sender from its counts, the receiver
+    // from the headers it got, both from their own exchange number and hold state).  Here the neighbour is an engine of this process, so its
+    // plan is compared directly -- what sph_slab_step_finish does with the plans it receives over RCCL.  A call issued on one engine only
+    // (an impulse, a member edit, a skipped step) ends HERE, with its name, not in a truncated copy.
+    if (!e->intentValid) return fail(SPH_ERR_STATE, "no plan for this exchange (sph_slab_step_begin did not run to its end)");
+    for (int d = 0; d < 2; ++d) {
+        SphEngine* nb = d ? hi : lo;
+        if (!nb) continue;
+        char why[320];
+        if (!nb->intentValid || slab_intent_mismatch(e->intent, nb->intent, d, why, sizeof(why))) {
+            if (!nb->intentValid) snprintf(why, sizeof(why), "the %s neighbour engine has no plan for this exchange", d ? "upper" : "lower");
+            e->stepPending = false;                          // (the step cannot be finished: destroy the group or prime it again)
+            return fail(SPH_ERR_STATE, "slab exchange %u refused before any record moved: %s", e->intent.exchangeNo, why);
+        }
+    }
     // the neighbour's send face -> this engine's receive face: header + migrants in use, halo copies in use (what sph_slab_step_finish
     // sends with ncclSend / ncclRecv), behind the neighbour's pack
     for (int d = 0; d < 2; ++d) {
@@ -1688,36 +1797,119 @@ static int slab_check_comm(SphEngine* e, SphComm* c) {
     }
     return SPH_OK;
 }
-// the grouped ncclSend / ncclRecv with the (at most two) z-neighbours: per direction the header + the migrants in use, and the halo
-// copies in use (sizes: slab_size_messages; both ends of a link derive them from the same counts)
+// The grouped ncclSend / ncclRecv of one exchange's faces: per neighbour TWO send / receive pairs in ONE group -- header + the migrants in use, and the
+// halo copies in use -- of unequal sizes.  One routine for the engine's exchange (slab_transfer_rccl) and for the self-test that runs exactly this
+// pattern on a one-GPU box with the rank itself as both neighbours (sph_comm_selftest_faces): ncclSend / ncclRecv to one peer match in issue order.
+static int rccl_post_faces(SphComm* c, hipStream_t st, const int peer[2], const bool has[2], char* const sendFace[2], char* const recvFace[2],
+                           const uint32_t msgSend[4], const uint32_t msgRecv[4], uint32_t faceCap) {
+    if (!has[0] && !has[1]) return SPH_OK;
+    const size_t hoff = slab_face_halo_off(faceCap);
+    NCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int d = 0; d < 2 && r == ncclSuccess; ++d) {
+        if (!has[d]) continue;
+        r = g_rccl.Send(sendFace[d], sizeof(SlabHdr) + (size_t)msgSend[2 + d] * 64u, ncclUint8, peer[d], c->comm, st);
+        if (r == ncclSuccess) r = g_rccl.Send(sendFace[d] + hoff, (size_t)msgSend[d] * 40u, ncclUint8, peer[d], c->comm, st);
+        if (r == ncclSuccess) r = g_rccl.Recv(recvFace[d], sizeof(SlabHdr) + (size_t)msgRecv[2 + d] * 64u, ncclUint8, peer[d], c->comm, st);
+        if (r == ncclSuccess) r = g_rccl.Recv(recvFace[d] + hoff, (size_t)msgRecv[d] * 40u, ncclUint8, peer[d], c->comm, st);
+    }
+    ncclResult_t g = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fail(SPH_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
+    if (g != ncclSuccess) return fail(SPH_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(g));
+    return SPH_OK;
+}
 static int slab_transfer_rccl(SphEngine* e, SphComm* c, hipStream_t st) {
-    if (e->hasLo || e->hasHi) {
-        const size_t hoff = slab_face_halo_off(e->faceCap);
-        NCCL_TRY(g_rccl.GroupStart());
-        ncclResult_t r = ncclSuccess;
-        for (int d = 0; d < 2 && r == ncclSuccess; ++d) {
-            if (!(d ? e->hasHi : e->hasLo)) continue;
-            const int peer = d ? c->rank + 1 : c->rank - 1;
-            r = g_rccl.Send(e->d_face[d], sizeof(SlabHdr) + (size_t)e->msgSend[2 + d] * 64u, ncclUint8, peer, c->comm, st);
-            if (r == ncclSuccess) r = g_rccl.Send(e->d_face[d] + hoff, (size_t)e->msgSend[d] * 40u, ncclUint8, peer, c->comm, st);
-            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2 + d], sizeof(SlabHdr) + (size_t)e->msgRecv[2 + d] * 64u, ncclUint8, peer, c->comm, st);
-            if (r == ncclSuccess) r = g_rccl.Recv(e->d_face[2 + d] + hoff, (size_t)e->msgRecv[d] * 40u, ncclUint8, peer, c->comm, st);
-        }
-        ncclResult_t g = g_rccl.GroupEnd();
-        if (r != ncclSuccess) return fail(SPH_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
-        if (g != ncclSuccess) return fail(SPH_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(g));
+    const int peer[2] = {c->rank - 1, c->rank + 1};
+    const bool has[2] = {e->hasLo != 0, e->hasHi != 0};
+    char* const sendFace[2] = {e->d_face[0], e->d_face[1]};
+    char* const recvFace[2] = {e->d_face[2], e->d_face[3]};
+    return rccl_post_faces(c, st, peer, has, sendFace, recvFace, e->msgSend, e->msgRecv, e->faceCap);
+}
+// A wait for a neighbour that cannot hang the host: the event is polled, and after `seconds` the call fails (SPH_ERR_TIMEOUT).  The work behind the
+// event is then still queued on the device (a receive whose sender never came): the process has to end; nothing can be re-posted on this communicator.
+static int wait_event_deadline(hipEvent_t ev, double seconds, float* waitedMs) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waitedMs) *waitedMs = (float)(el * 1e3);
+        if (q == hipSuccess) return SPH_OK;
+        if (q != hipErrorNotReady) return fail(SPH_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        if (el > seconds) return SPH_ERR_TIMEOUT;
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+    }
+}
+// The fixed-size message that precedes the sized ones: every rank sends its PLAN (64 bytes, slab_plan) to its neighbours and receives theirs.  Its size
+// depends on nothing, so it cannot be mismatched.
+static int rccl_post_plans(SphComm* c, hipStream_t st, const int peer[2], const bool has[2], uint32_t* d_plans /* 48 words: mine, from lo, from hi */) {
+    if (!has[0] && !has[1]) return SPH_OK;
+    NCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int d = 0; d < 2 && r == ncclSuccess; ++d) {
+        if (!has[d]) continue;
+        r = g_rccl.Send(d_plans, sizeof(SphSlabIntent), ncclUint8, peer[d], c->comm, st);
+        if (r == ncclSuccess) r = g_rccl.Recv(d_plans + 16 * (1 + d), sizeof(SphSlabIntent), ncclUint8, peer[d], c->comm, st);
+    }
+    ncclResult_t g = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fail(SPH_ERR_HIP, "ncclSend / ncclRecv of the plans failed: %s", g_rccl.GetErrorString(r));
+    if (g != ncclSuccess) return fail(SPH_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(g));
+    return SPH_OK;
+}
+static int ensure_handshake(SphEngine* e) {
+    if (e->hstream) return SPH_OK;
+    int rc;
+    if ((rc = dev_alloc(&e->d_intent, 48))) return rc;
+    HIP_TRY(hipHostMalloc((void**)&e->h_intent, 48 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&e->evIntent, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&e->hstream, hipStreamNonBlocking));
+    return SPH_OK;
+}
+// BEFORE a sized message of this exchange is posted: the plans cross each link and are compared on the host (SPH_SLAB_VERIFY 1, the default).  What this
+// costs: one more grouped send / receive of 64 bytes per neighbour on a stream of its own, and a host wait until the neighbours have reached the same
+// exchange -- which bounds the host's look-ahead to about one exchange (the device still holds more than a substep of queued work meanwhile).  What it
+// buys: two ranks whose host-side state went apart (an impulse, a member edit, an upload or a skipped step on one rank only) get an error with the
+// difference by name on BOTH ranks, where the sized ncclSend / ncclRecv would have hung or cut records off; and a neighbour that never arrives is a
+// timeout with this rank's step and sizes, not a hang.
+static int slab_handshake_rccl(SphEngine* e, SphComm* c) {
+    if (!e->verifyMode || !(e->hasLo || e->hasHi)) return SPH_OK;
+    if (!e->intentValid) return fail(SPH_ERR_STATE, "no plan for this exchange");
+    int rc;
+    if ((rc = ensure_handshake(e))) return rc;
+    std::memcpy(e->h_intent, &e->intent, sizeof(SphSlabIntent));
+    std::memset(e->h_intent + 16, 0, 2 * sizeof(SphSlabIntent));
+    HIP_TRY(hipMemcpyAsync(e->d_intent, e->h_intent, 48 * sizeof(uint32_t), hipMemcpyHostToDevice, e->hstream));
+    const int peer[2] = {c->rank - 1, c->rank + 1};
+    const bool has[2] = {e->hasLo != 0, e->hasHi != 0};
+    if ((rc = rccl_post_plans(c, e->hstream, peer, has, e->d_intent))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_intent + 16, e->d_intent + 16, 2 * sizeof(SphSlabIntent), hipMemcpyDeviceToHost, e->hstream));
+    HIP_TRY(hipEventRecord(e->evIntent, e->hstream));
+    rc = wait_event_deadline(e->evIntent, e->deadlineSec, &e->handshakeMs);
+    e->handshakes += 1u;
+    if (rc == SPH_ERR_TIMEOUT)
+        return fail(SPH_ERR_TIMEOUT, "rank %d of %d: no plan from a neighbour within %.1f s at exchange %u (step %u; this rank would send %u + %u records down, %u + %u up): "
+                                     "a neighbour rank is not making the same calls, or is gone.  The receive stays queued on the device: end this process.",
+                    c->rank, c->world, e->deadlineSec, e->intent.exchangeNo, e->stepNo, e->intent.sendHalo[0], e->intent.sendMig[0], e->intent.sendHalo[1], e->intent.sendMig[1]);
+    if (rc) return rc;
+    for (int d = 0; d < 2; ++d) {
+        if (!has[d]) continue;
+        SphSlabIntent nb;
+        std::memcpy(&nb, e->h_intent + 16 * (1 + d), sizeof(nb));
+        char why[320];
+        if (slab_intent_mismatch(e->intent, nb, d, why, sizeof(why)))
+            return fail(SPH_ERR_STATE, "rank %d of %d: slab exchange %u refused before any record moved: %s", c->rank, c->world, e->intent.exchangeNo, why);
     }
     return SPH_OK;
 }
-// One halo exchange of a substep: pack -> one grouped ncclSend / ncclRecv per z-neighbour -> unpack, all enqueued on the
-// engine's stream: no host synchronisation on the path (the message sizes come from counts that are two exchanges old), and the
-// stream order makes the unpack wait for the receives and the next pack wait for the sends.
+// One halo exchange of a substep: plan -> (the plans cross the links and are compared) -> pack -> per z-neighbour two grouped ncclSend / ncclRecv pairs -> unpack,
+// enqueued on the engine's stream; the stream order makes the unpack wait for the receives and the next pack wait for the sends.  With SPH_SLAB_VERIFY 0
+// there is no host wait on the path at all (the sizes come from counts that are two exchanges old).
 int sph_slab_exchange(SphEngine* e, SphComm* c) {
     int rc;
     if ((rc = slab_check_comm(e, c))) return rc;
     if (e->stepPending) return fail(SPH_ERR_STATE, "a boundary-first step is pending: finish it with sph_slab_step_finish");
     if (e->params.param_pause) return SPH_OK;                // the paused sph_dispatch that follows is a no-op: the halo records in place stay valid
-    if ((rc = slab_size_messages(e))) return rc;
+    if ((rc = slab_plan(e))) return rc;
+    if ((rc = slab_handshake_rccl(e, c))) return rc;
     if ((rc = slab_pack_on(e, e->stream))) return rc;
     if ((rc = slab_transfer_rccl(e, c, e->stream))) return rc;
     if ((rc = slab_unpack_on(e, e->stream, e->d_face[2], e->d_face[3], e->faceCap, e->msgRecv))) return rc;
@@ -1730,7 +1922,7 @@ int sph_slab_step_finish(SphEngine* e, SphComm* c) {
     if ((rc = slab_check_comm(e, c))) return rc;
     if (!e->stepPending) return fail(SPH_ERR_STATE, "sph_slab_step_finish without sph_slab_step_begin");
     if (e->stepPaused) { e->stepPending = false; return SPH_OK; }
-    if ((rc = slab_size_messages(e))) return rc;
+    if ((rc = slab_handshake_rccl(e, c))) { e->stepPending = false; return rc; }   // (the plan is sph_slab_step_begin's)
     if ((rc = slab_transfer_rccl(e, c, e->xstream))) return rc;
     if (e->optTiming) HIP_TRY(hipEventRecord(e->evX[3], e->xstream));
     if ((rc = slab_unpack_on(e, e->xstream, e->d_face[2], e->d_face[3], e->faceCap, e->msgRecv))) return rc;
@@ -1738,11 +1930,147 @@ int sph_slab_step_finish(SphEngine* e, SphComm* c) {
     return slab_step_join(e);
 }
 
+// ---- the agreement protocol's knobs and its view from outside ----
+int sph_slab_set_verify(SphEngine* e, int mode) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (mode < 0 || mode > 1) return fail(SPH_ERR_ARG, "verify mode %d: 1 = the plans cross the links before every sized exchange (default), 0 = off", mode);
+    e->verifyMode = mode;
+    return SPH_OK;
+}
+int sph_slab_set_deadline(SphEngine* e, double seconds) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    if (!(seconds > 0.0)) return fail(SPH_ERR_ARG, "deadline must be > 0 s");
+    e->deadlineSec = seconds;
+    return SPH_OK;
+}
+int sph_slab_plan(const SphEngine* e, SphSlabIntent* out, float* handshakeMsOut) {
+    if (!e || !out) return fail(SPH_ERR_ARG, "null argument");
+    if (!e->slab) return fail(SPH_ERR_STATE, "not a slab engine");
+    if (!e->intentValid) return fail(SPH_ERR_STATE, "no sized exchange has been planned yet");
+    *out = e->intent;
+    if (handshakeMsOut) *handshakeMsOut = e->handshakeMs;
+    return SPH_OK;
+}
+int sph_slab_plans_agree(const SphSlabIntent* mine, const SphSlabIntent* neighbour, int side, char* why, size_t whyBytes) {
+    if (!mine || !neighbour || side < 0 || side > 1) return fail(SPH_ERR_ARG, "bad argument");
+    char buf[320];
+    buf[0] = 0;
+    const bool bad = slab_intent_mismatch(*mine, *neighbour, side, buf, sizeof(buf));
+    if (why && whyBytes) { std::strncpy(why, buf, whyBytes - 1); why[whyBytes - 1] = 0; }
+    return bad ? 0 : 1;
+}
+int sph_slab_debug_tight_messages(SphEngine* e, int on) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    e->tightMessages = on ? 1 : 0;
+    return SPH_OK;
+}
+// Exactly the engine's exchange pattern over RCCL on ONE rank (the rank is its own lower and upper neighbour): the 64-byte plans first (with the
+// polled, deadline-bounded wait of the handshake), then rccl_post_faces -- the routine slab_transfer_rccl calls -- with two send / receive pairs of
+// UNEQUAL sizes per neighbour in one group, and every byte compared afterwards: what arrived is what was sent, nothing beyond a message was touched.
+int sph_comm_selftest_faces(SphComm* c, uint32_t faceCap, const uint32_t counts[4] /* halo lo, halo hi, migrants lo, migrants hi */, float* msOut) {
+    if (!c || !c->comm || !counts) return fail(SPH_ERR_ARG, "null argument");
+    if (faceCap == 0 || faceCap > (1u << 24)) return fail(SPH_ERR_ARG, "face capacity %u out of range", faceCap);
+    for (int i = 0; i < 4; ++i) if (counts[i] > faceCap) return fail(SPH_ERR_ARG, "count %u > face capacity %u", counts[i], faceCap);
+    const size_t fb = slab_face_bytes(faceCap), hoff = slab_face_halo_off(faceCap);
+    char* face[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_plans = nullptr;
+    hipStream_t st = nullptr, hs = nullptr;
+    hipEvent_t ev = nullptr, t0 = nullptr, t1 = nullptr;
+    auto cleanup = [&]() {
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        if (hs) { (void)hipStreamSynchronize(hs); (void)hipStreamDestroy(hs); }
+        for (auto& f : face) if (f) (void)hipFree(f);
+        if (d_plans) (void)hipFree(d_plans);
+        for (hipEvent_t x : {ev, t0, t1}) if (x) (void)hipEventDestroy(x);
+    };
+    int rc = SPH_OK;
+    for (int i = 0; i < 4 && !rc; ++i) rc = dev_alloc(&face[i], fb);
+    if (!rc) rc = dev_alloc(&d_plans, 48);
+    if (rc) { cleanup(); return rc; }
+    hipError_t er = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipStreamCreateWithFlags(&hs, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreate(&t0);
+    if (er == hipSuccess) er = hipEventCreate(&t1);
+    std::vector<unsigned char> host[2];
+    for (int d = 0; d < 2 && er == hipSuccess; ++d) {
+        host[d].resize(fb);
+        for (size_t i = 0; i < fb; ++i) host[d][i] = (unsigned char)((i * 2654435761u + 977u * (unsigned)d + (i >> 11)) >> 7);
+        er = hipMemcpyAsync(face[d], host[d].data(), fb, hipMemcpyHostToDevice, st);
+        if (er == hipSuccess) er = hipMemsetAsync(face[2 + d], 0, fb, st);
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(st);
+    if (er != hipSuccess) { cleanup(); return fail(SPH_ERR_HIP, "self-test setup failed: %s", hipGetErrorString(er)); }
+    const int peer[2] = {c->rank, c->rank};
+    const bool has[2] = {true, true};
+    // the plans
+    uint32_t plans[48];
+    for (int i = 0; i < 48; ++i) plans[i] = i < 16 ? 0x504c0000u + (uint32_t)i : 0u;
+    er = hipMemcpyAsync(d_plans, plans, sizeof(plans), hipMemcpyHostToDevice, hs);
+    if (er == hipSuccess) er = hipStreamSynchronize(hs);
+    if (er != hipSuccess) { cleanup(); return fail(SPH_ERR_HIP, "self-test setup failed: %s", hipGetErrorString(er)); }
+    if ((rc = rccl_post_plans(c, hs, peer, has, d_plans))) { cleanup(); return rc; }
+    (void)hipEventRecord(ev, hs);
+    float waited = 0.0f;
+    rc = wait_event_deadline(ev, 20.0, &waited);
+    if (rc) { cleanup(); return rc == SPH_ERR_TIMEOUT ? fail(SPH_ERR_TIMEOUT, "the plans' send / receive to self did not complete within 20 s") : rc; }
+    uint32_t back[48];
+    er = hipMemcpy(back, d_plans, sizeof(back), hipMemcpyDeviceToHost);
+    if (er != hipSuccess) { cleanup(); return fail(SPH_ERR_HIP, "self-test copy back failed: %s", hipGetErrorString(er)); }
+    for (int i = 0; i < 32; ++i)
+        if (back[16 + i] != plans[i & 15]) { cleanup(); return fail(SPH_ERR_HIP, "a 64-byte plan sent to self arrived wrong at word %d", i); }
+    // the faces: the sizes a receiver posts are the sizes the matching sender uses (what the plans' comparison guarantees between two ranks)
+    (void)hipEventRecord(t0, st);
+    if ((rc = rccl_post_faces(c, st, peer, has, face, face + 2, counts, counts, faceCap))) { cleanup(); return rc; }
+    (void)hipEventRecord(t1, st);
+    rc = wait_event_deadline(t1, 60.0, nullptr);
+    if (rc) { cleanup(); return rc == SPH_ERR_TIMEOUT ? fail(SPH_ERR_TIMEOUT, "the face messages to self did not complete within 60 s") : rc; }
+    if (msOut) { *msOut = 0.0f; (void)hipEventElapsedTime(msOut, t0, t1); }
+    std::vector<unsigned char> got(fb);
+    for (int d = 0; d < 2; ++d) {
+        er = hipMemcpy(got.data(), face[2 + d], fb, hipMemcpyDeviceToHost);
+        if (er != hipSuccess) { cleanup(); return fail(SPH_ERR_HIP, "self-test copy back failed: %s", hipGetErrorString(er)); }
+        const size_t migEnd = sizeof(SlabHdr) + (size_t)counts[2 + d] * 64u, haloEnd = hoff + (size_t)counts[d] * 40u;
+        for (size_t i = 0; i < fb; ++i) {
+            const bool sent = i < migEnd || (i >= hoff && i < haloEnd);
+            const unsigned char want = sent ? host[d][i] : (unsigned char)0;
+            if (got[i] != want) { cleanup(); return fail(SPH_ERR_HIP, "face %d: byte %zu of %zu is %u, expected %u (%s a message)", d, i, fb, got[i], want, sent ? "inside" : "beyond"); }
+        }
+    }
+    cleanup();
+    return SPH_OK;
+}
+
 int sph_sync(SphEngine* e) {
     if (!e) return fail(SPH_ERR_ARG, "null engine");
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->xstream) HIP_TRY(hipStreamSynchronize(e->xstream));
     return SPH_OK;
+}
+// sph_sync that cannot hang: the engine's streams are polled, and after `seconds` (<= 0: the engine's deadline, sph_slab_set_deadline) the call fails with
+// SPH_ERR_TIMEOUT and says where this engine stands.  For multi-rank hosts (bench.py --gpus N, halo.SlabSimulation): a transfer whose peer never posted
+// its half keeps the stream busy for ever; the host prints the message and ends the process (a fresh process, never a re-exec).
+int sph_sync_deadline(SphEngine* e, double seconds) {
+    if (!e) return fail(SPH_ERR_ARG, "null engine");
+    const double limit = seconds > 0.0 ? seconds : e->deadlineSec;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t sts[4] = {e->stream, e->xstream, e->bstream, e->hstream};
+    for (unsigned spins = 0;; ++spins) {
+        bool busy = false;
+        for (hipStream_t st : sts) {
+            if (!st) continue;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) busy = true;
+            else if (q != hipSuccess) return fail(SPH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        }
+        if (!busy) return SPH_OK;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > limit)
+            return fail(SPH_ERR_TIMEOUT, "the engine's streams did not drain within %.1f s (boundary-first steps begun %u, sized exchanges enqueued %u, last plan: %u + %u records down, %u + %u up): "
+                                         "a transfer is waiting for a neighbour rank that never posted its half.  End this process.",
+                        limit, e->stepNo, e->exchangeNo, e->intent.sendHalo[0], e->intent.sendMig[0], e->intent.sendHalo[1], e->intent.sendMig[1]);
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100)); else std::this_thread::yield();
+    }
 }
 
 int sph_kernel_times(SphEngine* e, double msOut[SPH_K_COUNT], int64_t launchesOut[SPH_K_COUNT], int reset) {

@@ -777,7 +777,9 @@ struct HaloRec {
 };
 static_assert(sizeof(HaloRec) == 40, "HaloRec is 40 bytes");
 struct SlabHdr {                                        // first 64 bytes of a face buffer / of the migrant message
-    uint32_t magic, nHalo, nHaloTrue, nMig, nMigTrue, exchange, pad[10];
+    uint32_t magic, nHalo, nHaloTrue, nMig, nMigTrue, exchange;
+    uint32_t msgHalo, msgMig;                           // round 5: records the SENDER's two messages of this exchange carry (the receiver compares them with what it sized its receives for: flag 32)
+    uint32_t pad[8];
 };
 static_assert(sizeof(SlabHdr) == 64, "SlabHdr is 64 bytes");
 // A face buffer of capacity cap: [SlabHdr][cap x SlabRec migrants][cap x HaloRec halo copies].  Two messages per direction and
@@ -906,10 +908,13 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const SlabRec* __restric
 constexpr uint32_t kSlabMagic = 0x48414c4fu;            // "HALO": first word of a face's header
 // counters[4], the exchange's flags -- bit 0: a send face overflowed, bit 1: the slab's slot capacity overflowed on unpack, bit 2: a received
 // face did not start with a valid header, bit 3: the sender had more records than its message carried, bit 4 (16, a notice): a particle crossed more
-// cell layers within one substep than the exchange follows (slab_check_layer_move, slab_record_misplaced).
+// cell layers within one substep than the exchange follows (slab_check_layer_move, slab_record_misplaced), bit 5 (32, round 5): the two ends of a
+// link sized this exchange's messages differently (the header says what the sender's messages carry; the receiver's sizes come out of its own plan).
 // ---- round 4: the compact faces (SlabFace layout above).  counters: [8] halo copies for lo, [9] for hi, [10] migrants for lo, [11] for hi
 // (running, reset here), [12..15] the same four of the last pack (sph_slab_status / the host's message sizing), [7] exchanges so far.
-__global__ void k_slab_headers2(uint32_t* __restrict__ counters, char* __restrict__ faceLo, char* __restrict__ faceHi, uint32_t cap) {
+// msgHalo* / msgMig*: the records this engine's messages of THIS exchange will carry (the host's plan, slab_plan in sph_engine.hip).
+__global__ void k_slab_headers2(uint32_t* __restrict__ counters, char* __restrict__ faceLo, char* __restrict__ faceHi, uint32_t cap,
+                                uint32_t msgHaloLo, uint32_t msgMigLo, uint32_t msgHaloHi, uint32_t msgMigHi) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t ex = counters[7];
     for (int d = 0; d < 2; ++d) {
@@ -919,7 +924,8 @@ __global__ void k_slab_headers2(uint32_t* __restrict__ counters, char* __restric
         if (f) {
             SlabHdr h;
             h.magic = kSlabMagic; h.nHalo = min(nh, cap); h.nHaloTrue = nh; h.nMig = min(nm, cap); h.nMigTrue = nm; h.exchange = ex;
-            for (int i = 0; i < 10; ++i) h.pad[i] = 0u;
+            h.msgHalo = d ? msgHaloHi : msgHaloLo; h.msgMig = d ? msgMigHi : msgMigLo;
+            for (int i = 0; i < 8; ++i) h.pad[i] = 0u;
             *reinterpret_cast<SlabHdr*>(f) = h;
         }
         counters[12 + d] = nh; counters[14 + d] = nm;
@@ -930,14 +936,15 @@ __global__ void k_slab_headers2(uint32_t* __restrict__ counters, char* __restric
 }
 // What of a received face may be used: the header must be one, and the counts are cut to what the MESSAGES carried
 // (msgHalo / msgMig records: the receiver sized them from the sender's counts of two exchanges ago; more than that -> error bit 8).
-struct FaceCounts { uint32_t nHalo, nMig; bool bad, more; };
+struct FaceCounts { uint32_t nHalo, nMig; bool bad, more, sized; };
 __device__ __forceinline__ FaceCounts slab_face_counts(const char* __restrict__ face, uint32_t cap, uint32_t msgHalo, uint32_t msgMig) {
-    FaceCounts c{0u, 0u, false, false};
+    FaceCounts c{0u, 0u, false, false, false};
     if (!face) return c;
     const SlabHdr h = *reinterpret_cast<const SlabHdr*>(face);
     if (h.magic != kSlabMagic || h.nHalo > cap || h.nMig > cap) { c.bad = true; return c; }
     c.nHalo = min(h.nHalo, msgHalo); c.nMig = min(h.nMig, msgMig);
     c.more = h.nHaloTrue > c.nHalo || h.nMigTrue > c.nMig;
+    c.sized = h.msgHalo != msgHalo || h.msgMig != msgMig;      // the sender's messages carried another number of records than this end received
     return c;
 }
 // Appends one received face behind slot counters[2] (+ `before` records of the face unpacked first): halo copies, then migrants.
@@ -975,6 +982,7 @@ __global__ void k_slab_commit2(uint32_t* __restrict__ counters, const char* __re
     const FaceCounts a = slab_face_counts(recvLo, cap, msgHaloLo, msgMigLo), b = slab_face_counts(recvHi, cap, msgHaloHi, msgMigHi);
     if (a.bad || b.bad) err |= 4u;
     if (a.more || b.more) err |= 8u;
+    if (a.sized || b.sized) err |= 32u;
     add = a.nHalo + a.nMig + b.nHalo + b.nMig;
     if (err) atomicOr(&counters[4], err);
     counters[2] = min(counters[2] + add, slotCap);

@@ -79,6 +79,17 @@ SPH_OPT_GRAPH, SPH_OPT_GRAPH_LAUNCHES = 5, 6
 KERNEL_CLASSES = ("bin", "scan", "scatter", "sph", "writeback", "impulse", "other")
 
 # every symbol include/sph_abi.h declares (checked by tests/test_abi.py)
+class SphSlabIntent(C.Structure):
+    """The plan of one sized halo exchange (include/sph_abi.h SphSlabIntent): what both ends of a link must agree on before a record moves."""
+    _fields_ = [("magic", C.c_uint32), ("exchangeNo", C.c_uint32), ("stepNo", C.c_uint32), ("faceCap", C.c_uint32),
+                ("sendHalo", C.c_uint32 * 2), ("sendMig", C.c_uint32 * 2), ("recvHalo", C.c_uint32 * 2), ("recvMig", C.c_uint32 * 2),
+                ("holdEvents", C.c_uint32), ("paramsHash", C.c_uint32), ("flags", C.c_uint32), ("zRange", C.c_uint32)]
+
+
+assert C.sizeof(SphSlabIntent) == 64
+SPH_ERR_TIMEOUT = -5
+
+
 ABI_SYMBOLS = (
     "sph_abi_version", "sph_params_default", "sph_rotation_mat3", "sph_effective_half",
     "sph_compute_grid_extents", "sph_spawn_particles", "sph_last_error", "sph_create",
@@ -93,6 +104,8 @@ ABI_SYMBOLS = (
     "sph_slab_step_begin", "sph_slab_step_finish", "sph_slab_step_finish_local",
     "sph_slab_face_bytes", "sph_slab_clear_flags", "sph_slab_message_bytes", "sph_slab_message_records", "sph_slab_step_times",
     "sph_river_default", "sph_generate_river_terrain", "sph_spawn_river_particles", "sph_set_river", "sph_get_river",
+    "sph_slab_set_verify", "sph_slab_set_deadline", "sph_slab_plan", "sph_slab_plans_agree", "sph_sync_deadline",
+    "sph_slab_debug_tight_messages", "sph_comm_selftest_faces",
 )
 # sph_debug_counters (SPH_OPT_DEBUG bit 3): diagnostics of k_sph_walk / k_sph_list, summed over launches:
 # [0] candidate rows walked from global memory (window too large; k_sph_walk), [1] targets on an exact fallback sweep,
@@ -200,6 +213,13 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     L.sph_spawn_river_particles.argtypes = [pp, C.POINTER(SphRiver), vp, C.c_size_t, C.c_uint32, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]
     L.sph_set_river.argtypes = [vp, C.POINTER(SphRiver), vp]
     L.sph_get_river.argtypes = [vp, C.POINTER(SphRiver)]
+    L.sph_slab_set_verify.argtypes = [vp, C.c_int]
+    L.sph_slab_set_deadline.argtypes = [vp, C.c_double]
+    L.sph_slab_plan.argtypes = [vp, C.POINTER(SphSlabIntent), C.POINTER(C.c_float)]
+    L.sph_slab_plans_agree.argtypes = [C.POINTER(SphSlabIntent), C.POINTER(SphSlabIntent), C.c_int, C.c_char_p, C.c_size_t]
+    L.sph_sync_deadline.argtypes = [vp, C.c_double]
+    L.sph_slab_debug_tight_messages.argtypes = [vp, C.c_int]
+    L.sph_comm_selftest_faces.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("sph_last_error", "sph_num_particles", "sph_abi_version", "sph_fountain_default", "sph_river_default"):

@@ -115,8 +115,29 @@ class HipSlabEngine:
     def step_finish_local(self, lo: "HipSlabEngine | None", hi: "HipSlabEngine | None"):
         _eng._check(self._L.sph_slab_step_finish_local(self._h, lo._h if lo is not None else None, hi._h if hi is not None else None))
 
-    def sync(self):
-        _eng._check(self._L.sph_sync(self._h))
+    def sync(self, deadline=None):
+        """deadline (seconds): poll instead of block; a transfer whose neighbour never came raises (SPH_ERR_TIMEOUT) instead of hanging."""
+        if deadline is None:
+            _eng._check(self._L.sph_sync(self._h))
+        else:
+            _eng._check(self._L.sph_sync_deadline(self._h, float(deadline)))
+
+    # -- agreement of the two ends of a link (round 5) ----------------------------------------------------------
+    def set_verify(self, mode: int):
+        _eng._check(self._L.sph_slab_set_verify(self._h, int(mode)))
+
+    def set_deadline(self, seconds: float):
+        _eng._check(self._L.sph_slab_set_deadline(self._h, float(seconds)))
+
+    def plan(self):
+        """(SphSlabIntent of the last sized exchange, ms its handshake waited on the host)"""
+        out = _eng.SphSlabIntent()
+        ms = C.c_float()
+        _eng._check(self._L.sph_slab_plan(self._h, C.byref(out), C.byref(ms)))
+        return out, float(ms.value)
+
+    def debug_tight_messages(self, on: bool):
+        _eng._check(self._L.sph_slab_debug_tight_messages(self._h, 1 if on else 0))
 
     def status(self):
         """[records packed for lo, for hi, slots in use, -, flags]; raises for the flags that lost records (1, 2, 4, 8).  Flag 16 (a particle
@@ -198,6 +219,14 @@ class RcclComm:
         ms = C.c_float()
         _eng._check(self._L.sph_comm_selftest_timed(self._h, int(nbytes), C.byref(ms)))
         return nbytes / max(ms.value, 1e-6) / 1e6
+
+    def selftest_faces(self, face_cap: int, counts) -> float:
+        """The engine's exchange pattern with the rank as its own two neighbours (sph_comm_selftest_faces): plans first, then per neighbour
+        two send / receive pairs of unequal sizes in one group; every byte compared.  Returns the ms of the faces' group."""
+        ms = C.c_float()
+        arr = (C.c_uint32 * 4)(*[int(x) for x in counts])
+        _eng._check(self._L.sph_comm_selftest_faces(self._h, int(face_cap), arr, C.byref(ms)))
+        return float(ms.value)
 
     def close(self):
         if self._h:

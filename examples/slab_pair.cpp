@@ -102,9 +102,29 @@ int main(int argc, char** argv) {
                     (unsigned long long)bytes[0], (unsigned long long)bytes[1], (unsigned long long)(bytes[2] ? bytes[2] : bytes[3]));
     }
     std::printf("%zu of %zu particles, %zu differ from the single engine, %zu changed slab\n", got, n, bad, moved);
+    // The error path (round 5): an impulse issued on ONE rank only.  That rank plans whole faces for its next exchanges, its neighbour does not --
+    // over RCCL two sized ncclSend / ncclRecv that do not match (a hang, or records cut off).  Every sized exchange has a plan, and nothing moves
+    // before both ends of a link have compared theirs: sph_slab_step_finish_local looks at the neighbour engine's plan, sph_slab_step_finish
+    // sends the 64-byte plans across the link first.  Either way the step ends with SPH_ERR_STATE and the difference by name, on both ranks.
+    bool refused = false;
+    {
+        CHECK(sph_apply_wave_impulse(slab[0], 40.0f, 50.0f, 1.0f, dir, -3.4e38f, 3.4e38f));      // slab 0 only
+        for (auto* e : slab) CHECK(sph_slab_step_begin(e, -1.0f));
+        const int r0 = sph_slab_step_finish_local(slab[0], nullptr, slab[1]);
+        std::printf("one-sided impulse: finish(slab 0) -> %d: %s\n", r0, r0 ? sph_last_error() : "accepted");
+        const int r1 = sph_slab_step_finish_local(slab[1], slab[0], nullptr);
+        std::printf("one-sided impulse: finish(slab 1) -> %d: %s\n", r1, r1 ? sph_last_error() : "accepted");
+        refused = r0 == SPH_ERR_STATE && r1 == SPH_ERR_STATE;
+        SphSlabIntent a, b;
+        CHECK(sph_slab_plan(slab[0], &a, nullptr));
+        CHECK(sph_slab_plan(slab[1], &b, nullptr));
+        std::printf("plans of exchange %u: slab 0 has seen %u hold events and would send %u + %u records up, slab 1 has seen %u and expects %u + %u\n",
+                    a.exchangeNo, a.holdEvents, a.sendHalo[1], a.sendMig[1], b.holdEvents, b.recvHalo[0], b.recvMig[0]);
+        for (auto* e : slab) { uint32_t st[5]; CHECK(sph_slab_status(e, st)); if (st[4] & ~16u) refused = false; }   // nothing was cut off: nothing moved
+    }
     for (auto* e : slab) sph_destroy(e);
     sph_destroy(one);
-    const bool ok = got == n && bad == 0;
+    const bool ok = got == n && bad == 0 && refused;
     std::printf(ok ? "slab_pair OK\n" : "slab_pair FAILED\n");
     return ok ? 0 : 1;
 }

@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 3   /* 3: compact halo faces (40-byte halo copies, count-sized messages), jumps of up to 3 cell layers followed, sph_slab_clear_flags / _message_bytes / _step_times / _face_bytes, flag 16 no longer an error, SPH_OPT_NEIGHBOR_KERNEL 4 */
+#define SPH_ABI_VERSION 4   /* 4: the PLAN of a sized exchange (SphSlabIntent) compared between neighbours before any record moves: sph_slab_step_finish_local compares the
+                               neighbour engines' plans, the RCCL transport sends them across each link first (sph_slab_set_verify), waits with a deadline (SPH_ERR_TIMEOUT,
+                               sph_slab_set_deadline, sph_sync_deadline); flag 32; sph_slab_plan / _plans_agree, sph_comm_selftest_faces; SPH_OPT_NEIGHBOR_KERNEL 4 retired */
+/* (3: compact halo faces (40-byte halo copies, count-sized messages), jumps of up to 3 cell layers followed, sph_slab_clear_flags / _message_bytes / _step_times / _face_bytes, flag 16 no longer an error, SPH_OPT_NEIGHBOR_KERNEL 4) */
 /* (2: sph_slab_step_*, header validation of received halo messages, SPH_OPT_NEIGHBOR_KERNEL 3 (default), records on demand by default) */
 
 enum {
@@ -36,7 +39,9 @@ enum {
     SPH_ERR_ARG = -1,      /* bad argument / null handle                    */
     SPH_ERR_HIP = -2,      /* HIP runtime error (message has hipGetErrorString) */
     SPH_ERR_STATE = -3,    /* call not valid in the engine's current state   */
-    SPH_ERR_CAPACITY = -4  /* a fixed-capacity buffer (ghosts, migrants) overflowed */
+    SPH_ERR_CAPACITY = -4, /* a fixed-capacity buffer (ghosts, migrants) overflowed */
+    SPH_ERR_TIMEOUT = -5   /* a wait for a neighbour rank ran into its deadline (sph_slab_set_deadline): device work of this rank is still queued behind a
+                              transfer that will never complete; print sph_last_error() and end the process */
 };
 
 /* 80-byte particle record: struct SPHParticle, SPHFluid3D.h:12-24 (std430 twin:
@@ -338,6 +343,51 @@ int sph_comm_selftest(SphComm* comm, uint64_t bytes);
 /* The same, also returning the hipEvent time of the grouped send + receive alone (ms). */
 int sph_comm_selftest_timed(SphComm* comm, uint64_t bytes, float* msOut);
 int sph_slab_exchange(SphEngine* e, SphComm* comm);
+
+/* ---- agreement of the two ends of a link (round 5; no reference counterpart) -----------------------------------------
+ * The sizes of an exchange's messages are derived on each rank by itself: the sender from its own record counts of two exchanges ago, the
+ * receiver from the headers it received then, both from their own exchange number and from whether something stirred the fluid lately (an
+ * impulse, a container / grid edit, a priming exchange: "hold", whole faces for three exchanges).  That only agrees while every rank makes the
+ * same calls; ncclSend / ncclRecv with sizes that do not agree hang or cut records off.  So every sized exchange has a PLAN, 64 bytes: */
+typedef struct SphSlabIntent {
+    uint32_t magic;            /* "PLAN" */
+    uint32_t exchangeNo;       /* sized exchanges this engine has enqueued before this one */
+    uint32_t stepNo;           /* boundary-first steps begun */
+    uint32_t faceCap;
+    uint32_t sendHalo[2], sendMig[2];   /* records this engine's messages to the lower / upper neighbour carry */
+    uint32_t recvHalo[2], recvMig[2];   /* records it posts receives for, from the lower / upper neighbour */
+    uint32_t holdEvents;       /* impulses / container and grid edits / priming exchanges seen so far */
+    uint32_t paramsHash;       /* FNV-1a of the SphParams the exchange is planned under */
+    uint32_t flags;            /* 1 paused, 2 message test hook, 4 this exchange holds whole faces */
+    uint32_t zRange;           /* z0 | z1 << 16: the cell layers this engine owns */
+} SphSlabIntent;
+/* ... and nothing moves before the plans of both ends of every link have been compared:
+ *   - sph_slab_step_finish_local compares the neighbour ENGINES' plans directly;
+ *   - sph_slab_exchange / sph_slab_step_finish send the plan across each link as a FIXED-SIZE message on a stream of its own, wait for the
+ *     neighbours' plans on the host (polled, at most the deadline: SPH_ERR_TIMEOUT) and compare.  A difference is SPH_ERR_STATE on BOTH
+ *     ranks of the link, with what differs by name ("this rank has seen 4 impulses ..., the upper neighbour 3"), before a sized message is
+ *     posted.  Cost: one 64-byte send / receive per neighbour and exchange, and the host's look-ahead shrinks from two exchanges to about
+ *     one (the device still holds more than a substep of queued work while the host waits).  sph_slab_set_verify(engine, 0) switches it
+ *     off: then there is no host wait on the path beyond the pinned-memory read of counts that are two exchanges old, and agreement rests
+ *     on the ranks' call sequences being the same.
+ * Behind both there is a device-side check: a header names the sizes its sender's messages carry, the receiver's unpack compares them with the
+ * sizes it received: flag 32 (an error of sph_slab_status / sph_slab_download). */
+int sph_slab_set_verify(SphEngine* e, int mode /* 1 (default) | 0 */);
+/* Limit of every host-side wait for a neighbour (default 30 s). */
+int sph_slab_set_deadline(SphEngine* e, double seconds);
+/* The plan of the last sized exchange, and (nullable) the host time its handshake waited, in ms. */
+int sph_slab_plan(const SphEngine* e, SphSlabIntent* out, float* handshakeMsOut);
+/* Host-only: 1 if `neighbour` (the plan of the engine on side 0 = below / 1 = above of `mine`) fits `mine`, else 0 and the reason in `why`. */
+int sph_slab_plans_agree(const SphSlabIntent* mine, const SphSlabIntent* neighbour, int side, char* why, size_t whyBytes);
+/* sph_sync that cannot hang: polls the engine's streams; SPH_ERR_TIMEOUT after `seconds` (<= 0: the engine's deadline) with where this engine stands. */
+int sph_sync_deadline(SphEngine* e, double seconds);
+/* Test hook (replaces round 4's environment variable): messages carry the count of two exchanges ago, no margin, no calm rule. */
+int sph_slab_debug_tight_messages(SphEngine* e, int on);
+/* The engine's exchange pattern on ONE rank, the rank being its own lower and upper neighbour: first the 64-byte plans (with the handshake's
+ * polled wait), then the routine sph_slab_exchange itself posts the faces with -- per neighbour two ncclSend / ncclRecv pairs of UNEQUAL sizes
+ * in one group: header + counts[2 + d] migrants, counts[d] halo copies -- over faces of capacity faceCap filled with a pattern; every byte is
+ * compared (inside a message: arrived; beyond it: untouched).  msOut (nullable): hipEvent time of the faces' group. */
+int sph_comm_selftest_faces(SphComm* comm, uint32_t faceCap, const uint32_t counts[4], float* msOut);
 /* ---- boundary-first substep: the exchange hidden behind the interior of the SPH pass -----------------------------
  * sph_slab_step_begin = sph_dispatch, except that the SPH pass runs the slot ranges next to the slab's faces first (the
  * five lowest / five highest local cell layers: everything the next pack can touch as long as a substep moves a particle

@@ -22,7 +22,7 @@ def test_exports_match_header(pkg):
     assert sorted(pkg.ABI_SYMBOLS) == declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sph_abi_version() == 3
+    assert L.sph_abi_version() == 4
 
 
 def test_struct_layouts(pkg):
@@ -99,3 +99,52 @@ def test_slab_message_sizing_rule(pkg):
     assert f(10, 200, cap) == cap
     for seen, before in ((5000, 5100), (5100, 5000), (123456, 120000)):
         assert 0 < f(seen, before, cap) <= cap
+
+
+def _plan(pkg, **kw):
+    I = pkg.SphSlabIntent()
+    I.magic = 0x504c414e
+    I.exchangeNo, I.stepNo, I.faceCap = 7, 7, 5000
+    I.holdEvents, I.paramsHash, I.flags = 2, 0xabcdef01, 0
+    for k, v in kw.items():
+        cur = getattr(I, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(I, k, v)
+    return I
+
+
+def _agree(pkg, mine, nb, side):
+    why = C.create_string_buffer(320)
+    r = pkg.load_library().sph_slab_plans_agree(C.byref(mine), C.byref(nb), side, why, 320)
+    return r, why.value.decode()
+
+
+def test_plans_of_two_neighbours_agree_or_say_what_differs(pkg):
+    """The host logic that decides whether an exchange may move a record (sph_slab_plans_agree, what sph_slab_step_finish_local and
+    the RCCL handshake call): the lower rank owns layers [0, 8), the upper [8, 16); what one sends the other must expect, record for record."""
+    lo = _plan(pkg, zRange=0 | (8 << 16), sendHalo=(0, 1300), sendMig=(0, 1100), recvHalo=(0, 1250), recvMig=(0, 1024))
+    hi = _plan(pkg, zRange=8 | (16 << 16), sendHalo=(1250, 0), sendMig=(1024, 0), recvHalo=(1300, 0), recvMig=(1100, 0))
+    assert _agree(pkg, lo, hi, 1) == (1, "") and _agree(pkg, hi, lo, 0) == (1, "")
+    cases = [("exchangeNo", 8, "exchange"), ("holdEvents", 3, "one rank only"), ("paramsHash", 5, "members"), ("faceCap", 4096, "face capacity"),
+             ("flags", 4, "hold"), ("magic", 0, "no plan"), ("zRange", 9 | (16 << 16), "not adjacent")]
+    for field, value, word in cases:
+        bad = _plan(pkg, zRange=8 | (16 << 16), sendHalo=(1250, 0), sendMig=(1024, 0), recvHalo=(1300, 0), recvMig=(1100, 0), **{field: value}) if field != "zRange" else \
+            _plan(pkg, zRange=value, sendHalo=(1250, 0), sendMig=(1024, 0), recvHalo=(1300, 0), recvMig=(1100, 0))
+        r, why = _agree(pkg, lo, bad, 1)
+        assert r == 0 and word in why, (field, why)
+        if field != "magic":                                    # (an engine's own plan always carries the magic)
+            r2, why2 = _agree(pkg, bad, lo, 0)                  # ... and the other end of the link refuses too
+            assert r2 == 0 and why2, (field, why2)
+    # sizes: a sender that holds whole faces against a receiver that does not (the one-sided impulse of VERDICT r04)
+    whole = _plan(pkg, zRange=8 | (16 << 16), sendHalo=(5000, 0), sendMig=(5000, 0), recvHalo=(5000, 0), recvMig=(5000, 0))
+    r, why = _agree(pkg, lo, whole, 1)
+    assert r == 0 and "will send 5000 halo copies + 5000 migrants, this rank expects 1250 + 1024" in why, why
+    r, why = _agree(pkg, whole, lo, 0)
+    assert r == 0 and "expects" in why
+    # one direction only
+    short = _plan(pkg, zRange=8 | (16 << 16), sendHalo=(1250, 0), sendMig=(1024, 0), recvHalo=(1299, 0), recvMig=(1100, 0))
+    r, why = _agree(pkg, lo, short, 1)
+    assert r == 0 and "this rank will send 1300 halo copies + 1100 migrants" in why and "expects 1299 + 1100" in why, why

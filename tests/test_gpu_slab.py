@@ -342,6 +342,11 @@ def bcast(b):
 comm = halo.RcclComm(0, 1, bcast)
 for nbytes in (64, 1 << 20, (209716 + 1) * 64):          # the last: one face message of the weak-scaling slab (1.6 layers of 256 x 256 cells)
     comm.selftest(nbytes)
+# the engine's own exchange pattern (round 5): the 64-byte plans with the handshake's polled wait, then the routine sph_slab_exchange posts its faces
+# with -- per neighbour two send / receive pairs of UNEQUAL sizes in one group -- with the rank as both of its neighbours; every byte compared
+for cap, counts in ((1024, (0, 0, 0, 0)), (1024, (1, 1024, 1024, 0)), (8192, (3000, 2900, 17, 411)), (217908, (163840, 171000, 5200, 900))):
+    ms = comm.selftest_faces(cap, counts)
+    print("faces", cap, counts, round(ms, 3), "ms")
 comm.close()
 dist.destroy_process_group()
 print("SELFTEST OK")
@@ -508,36 +513,116 @@ def test_step_times_say_whether_the_exchange_was_hidden(pkg, oracle):
 
 
 def test_a_message_that_turns_out_too_small_is_reported(pkg, oracle):
-    """Messages are sized from the counts of two exchanges ago + 25 % + 1024 records.  With the margin taken away (test hook
-    SPH_SLAB_MSG_MARGIN0=1, read when the library first sizes a message: own process) any growth of a face's record count cuts
-    records off -- which must be LOUD (error flag 8: sph_slab_status / sph_slab_download fail), never silent."""
-    import subprocess
-    code = r'''
-import importlib, os, sys
-import numpy as np
-sys.path.insert(0, os.path.join(%r, "tests"))
-from conftest import PKG_NAME, small_scene, to_oracle_params
-pkg = importlib.import_module(PKG_NAME)
-halo = importlib.import_module(PKG_NAME + ".halo")
-import torch
-rec, sp = small_scene(pkg, n=6000, grid=20, seed=51)
-g = pkg.compute_grid_extents(sp)
-cz = np.clip(np.floor(((rec["pos"][:, 2] - np.float32(g.gridMin[2])) / np.float32(g.cellSize)).astype(np.float32)), 0, g.dims[2] - 1).astype(np.int64)
-ids = np.arange(len(rec), dtype=np.uint32)
-mk = lambda p, i, prm, z0, z1, lo, hi: halo.HipSlabEngine(p, i, prm, z0, z1, lo, hi, capacity=len(rec) * 2 + 8192)
-grp = halo.SlabGroup.from_particles(rec, ids, sp, tuple(g.dims), 2, mk, lambda n: torch.zeros((n, halo.REC_WORDS), dtype=torch.float32, device="cuda"), 8192, cz)
-grp.enable_overlap(8192)
-for s in range(8):
-    if s == 4:
-        grp.ApplyWaveImpulse(40.0, 50.0, 1.0, (0.0, 0.0, 1.0), -1e9, 1e9)      # a kick along z: the faces' record counts change
-    grp.DispatchCompute()
-try:
-    for x in grp.sims:
-        x.engine.status()
-    print("SILENT")
-except pkg.SphError as ex:
-    print("LOUD", ex)
-''' % ROOT
-    env = dict(os.environ, SPH_SLAB_MSG_MARGIN0="1")
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
-    assert "LOUD" in res.stdout and "more halo records than its message" in res.stdout, res.stdout + res.stderr
+    """Messages are sized from the counts of two exchanges ago + 25 % + 1024 records.  With the margin and the calm / hold rules taken away
+    (sph_slab_debug_tight_messages on EVERY engine: the hook is part of the plan, so both ends of a link still agree) any growth of a face's
+    record count cuts records off -- which must be LOUD (error flag 8: sph_slab_status / sph_slab_download fail), never silent."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    rec, sp = small_scene(pkg, n=6000, grid=20, seed=51)
+    grp = _group(pkg, halo, rec, sp, 2)
+    grp.enable_overlap(8192)
+    for s in grp.sims:
+        s.engine.debug_tight_messages(True)
+    for step in range(8):
+        if step == 4:
+            grp.ApplyWaveImpulse(40.0, 50.0, 1.0, (0.0, 0.0, 1.0), -1e9, 1e9)      # a kick along z: the faces' record counts change
+        grp.DispatchCompute()
+    with pytest.raises(pkg.SphError, match="more halo records than its message"):
+        for x in grp.sims:
+            x.engine.status()
+
+
+def _primed_calm_group(pkg, oracle, halo, world=3, steps=6):
+    """A group whose faces are calm: its exchanges are SIZED (not whole faces), so the two ends of a link really depend on each other's state."""
+    P, sp = small_scene(pkg, n=15000, grid=24, seed=51)
+    op = to_oracle_params(oracle, sp)
+    grp = _group(pkg, halo, P, sp, world)
+    grp.enable_overlap(20000)
+    want = P
+    for _ in range(steps):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+    plans = [s.engine.plan()[0] for s in grp.sims]
+    assert all(p.sendHalo[1] < 20000 for p in plans[:-1]) and all(p.flags == 0 for p in plans), [(list(p.sendHalo), p.flags) for p in plans]
+    return P, sp, op, grp, want
+
+
+def test_the_plans_of_neighbouring_engines_agree_on_every_step(pkg, oracle):
+    """What sph_slab_step_finish_local asserts before it copies anything: the neighbour's send sizes, computed from the
+    NEIGHBOUR's state, equal this engine's receive sizes, computed from the headers it received -- on whole-face exchanges and on sized ones."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op, grp, want = _primed_calm_group(pkg, oracle, halo)
+    L = pkg.load_library()
+    import ctypes as C
+    for _ in range(3):
+        grp.DispatchCompute(); want = oracle.substep(want, op)
+        plans = [s.engine.plan()[0] for s in grp.sims]
+        for r in range(len(plans) - 1):
+            why = C.create_string_buffer(320)
+            assert L.sph_slab_plans_agree(C.byref(plans[r]), C.byref(plans[r + 1]), 1, why, 320) == 1, why.value
+            assert L.sph_slab_plans_agree(C.byref(plans[r + 1]), C.byref(plans[r]), 0, why, 320) == 1, why.value
+            assert plans[r].sendHalo[1] == plans[r + 1].recvHalo[0] and plans[r].recvMig[1] == plans[r + 1].sendMig[0]
+            assert 0 < plans[r].sendHalo[1] < 20000                                  # sized, not whole faces
+    assert_records_equal(halo.merge_into_records(P, grp.download()), want, "3 slabs, sized exchanges, plans compared on every step")
+
+
+@pytest.mark.parametrize("what", ["kick", "member", "hook"])
+def test_a_call_on_one_engine_only_is_refused_by_name_before_any_record_moves(pkg, oracle, what):
+    """An impulse, a member edit or a test hook issued on ONE engine of a group makes that engine plan other message sizes (or other physics) than
+    its neighbours expect.  Over RCCL that is a hang or a truncated receive; here -- and in the RCCL handshake, which runs the same comparison on
+    the plans it receives -- it is SPH_ERR_STATE with the difference by name, raised by the finish of the very next step, on both ends of the link."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op, grp, want = _primed_calm_group(pkg, oracle, halo)
+    a, b, c = (s.engine for s in grp.sims)
+    if what == "kick":
+        b.apply_wave_impulse(40.0, 50.0, 1.0, (0.0, 0.0, 1.0), -1e9, 1e9)          # the middle engine only
+        word = "one rank only"
+    elif what == "member":
+        q = type(sp).from_buffer_copy(sp)
+        q.param_viscosity = 4.0
+        b._p = q                                                                     # (step_begin hands the engine its own members)
+        word = "members"
+    else:
+        b.debug_tight_messages(True)
+        word = "hook"
+    for e in (a, b, c):
+        e.step_begin()
+    with pytest.raises(pkg.SphError, match=word):
+        a.step_finish_local(None, b)                                                 # the lower end of the link refuses ...
+    with pytest.raises(pkg.SphError, match=word):
+        b.step_finish_local(a, c)                                                    # ... and so does the engine that was kicked
+    with pytest.raises(pkg.SphError, match=word):
+        c.step_finish_local(b, None)
+    for e in (a, b, c):
+        assert e.status()[4] == 0                                                    # nothing was cut off, nothing overflowed: nothing moved
+
+
+def test_a_sized_exchange_after_the_box_moved_holds_whole_faces(pkg, oracle):
+    """sph_slab_exchange sized its messages before anything had noticed a grid / container edit.  The plan notices it now: the
+    exchange right after the box moved by a cell is planned with whole faces (flags bit 2), and the event is counted."""
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op = _scene(pkg, oracle, n=2400, grid=14, seed=53)
+    cz, dims = _cell_z(pkg, sp, P)
+    eng = halo.HipSlabEngine(P, np.arange(len(P), dtype=np.uint32), sp, 0, dims[2], False, False, capacity=len(P) + 4096)
+    eng.alloc_faces(1024)
+    comm = halo.RcclComm(0, 1, lambda b: b)
+    for _ in range(6):
+        eng.exchange(comm); eng.dispatch()
+    p0, _ = eng.plan()
+    assert p0.flags == 0 and p0.exchangeNo == 5
+    sp.param_boxCenter[0] = float(sp.param_boxCenter[0]) + float(sp.param_h)        # the grid moves by one cell
+    eng.exchange(comm)
+    p1, _ = eng.plan()
+    assert p1.flags & 4 and p1.holdEvents > p0.holdEvents and p1.exchangeNo == 6
+    eng.dispatch()
+    for _ in range(4):
+        eng.exchange(comm); eng.dispatch()
+    p2, _ = eng.plan()
+    assert p2.flags == 0                                                             # calm again
+    comm.close(); eng.close()
+
+
+def test_sync_with_a_deadline(pkg, oracle):
+    halo = importlib.import_module(PKG_NAME + ".halo")
+    P, sp, op, grp, want = _primed_calm_group(pkg, oracle, halo, world=2, steps=4)
+    for s in grp.sims:
+        s.engine.sync(deadline=30.0)
+    assert_records_equal(halo.merge_into_records(P, grp.download()), want, "2 slabs")
