@@ -253,7 +253,7 @@ def test_random_call_sequences_against_the_oracle(pkg, oracle, seed):
         f.close()
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(12)) + [5123, 5219])     # (5123, 5219: the two seeds of round 4's last sweep that raised a notice after a box move)
 def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
     """What a multi-GPU caller does between the substeps of a slab group -- wave impulses, live parameter edits, a container that
     changes shape under the fluid, time-step overrides -- in random order, with boundary-first steps: the merged records equal the
@@ -286,7 +286,7 @@ def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
     grp.enable_overlap(face)
     want, worst, log = rec.copy(), 0, []
     stepped = False                                          # (a sequence may draw no unpaused substep at all: the ghosts' records then stay as uploaded)
-    shifts = 0                                               # grid moves by a cell ("move"): each may add a layer to what the exchange has to follow at once
+    shifts = 0                                               # grid moves by a cell ("move") SINCE THE LAST UNPAUSED SUBSTEP: they add to what that substep's exchange has to follow at once
     moving = rec["isGhost"] != 1
     for _ in range(int(rng.integers(10, 18))):
         opn = rng.choice(["dispatch", "dispatch", "dispatch", "wave", "param", "shape", "pause", "move"])
@@ -310,7 +310,10 @@ def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
             grp.DispatchCompute(dt)
             stepped = True
             nxt = oracle.substep(want, op, dt=dt)
-            worst = max(worst, int(np.abs(layer(nxt) - layer(want))[moving].max(initial=0)))
+            # what THIS exchange had to follow: the substep's own jump + the cells the grid moved under the particles since the substep before
+            # (round 4 added the moves of the whole call sequence, which excused any notice after three moves: VERDICT r04)
+            worst = max(worst, int(np.abs(layer(nxt) - layer(want))[moving].max(initial=0)) + shifts)
+            shifts = 0
             want = nxt
         elif opn == "wave":
             a = (float(rng.uniform(0.2, 2.0)), float(rng.uniform(1.0, 4.0)), float(rng.uniform(0, 6.0)), (0.3, 1.0, -0.2), -1e9, 1e9)
@@ -339,10 +342,34 @@ def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
             reported.append(st)
     if reported:
         thin = min(s.z1 - s.z0 for s in grp.sims)
-        eff = worst + shifts
-        assert eff > 3 or (eff > 1 and world > 2 and thin <= eff), f"seed {seed}: largest layer jump {worst} + {shifts} grid moves (thinnest slab {thin}), yet flag 16: {what}: {log}"
+        eff = worst
+        assert eff > 3 or (eff > 1 and world > 2 and thin <= eff), f"seed {seed}: largest layer jump of one exchange (substep + grid moves before it) {worst} (thinnest slab {thin}), yet flag 16: {what}: {log}"
     else:
         got = halo.merge_into_records(rec, grp.download(), stepped=stepped)
         assert_records_equal(got, want, f"seed {seed} as {world} slabs: {what}: {log}")
+    # Whatever state the sequence left the group in (whole faces or sized messages, any exchange number): a call on ONE engine only must end the
+    # next step with SPH_ERR_STATE on both ends of that engine's links, before a record moves (the plans' comparison of sph_slab_step_finish_local).
+    if getattr(grp, "_primed", False) and not reported:
+        sp.param_pause = 0
+        grp.DispatchCompute()                                # (a grid that moved last: primed again here)
+        k = int(rng.integers(0, world))
+        kind = rng.choice(["kick", "member"])
+        if kind == "kick":
+            grp.sims[k].engine.apply_wave_impulse(60.0, 2.0, 0.5, (0.0, 0.3, 1.0), -1e9, 1e9)
+        else:
+            q = type(sp).from_buffer_copy(sp)
+            q.param_gasConstant = float(sp.param_gasConstant) * 1.5
+            grp.sims[k].engine._p = q
+        for s in grp.sims:
+            s.engine.step_begin()
+        for r, s in enumerate(grp.sims):
+            lo = grp.sims[r - 1].engine if r > 0 else None
+            hi = grp.sims[r + 1].engine if r < world - 1 else None
+            touches = abs(r - k) <= 1
+            if touches:
+                with pytest.raises(pkg.SphError, match="one rank only|members"):
+                    s.engine.step_finish_local(lo, hi)
+            else:
+                s.engine.step_finish_local(lo, hi)
     for s in grp.sims:
         s.engine.close()

@@ -50,3 +50,41 @@ def test_contract_stays_inside_the_references_own_spread(pkg, oracle):
     assert rows[3][1] < 1e-3 and rows[3][2] < 1e-3                                # 50 substeps: both pairs, same order of magnitude
     for _, d01, d02, _, _ in rows:
         assert d01 <= 10.0 * d02 + 1e-7                                            # never far outside the order-induced spread
+
+
+def test_settled_pool_whose_1_7e_4_it_is(pkg, oracle):
+    """north_star: "per-particle density / pressure within 1e-4 rel of the CPU reference after 100 substeps".  On the one scene where that is a
+    meaningful question -- the reference's default 50 000-particle scene settled into its pool (tests/golden/settled_pool.npz, written by
+    tests/golden/make_settled_pool.py) -- 100 substeps under the three oracle contracts from the same state:
+        density   literal vs engine contract 2.9e-5    literal vs the SHADER'S OWN second legal order 2.2e-5      (both inside 1e-4)
+        pressure  literal vs engine contract 1.75e-4   literal vs the shader's own second legal order 1.73e-4
+    The reference does not hold 1e-4 in pressure against ITSELF on this scene (its atomicExchange list order is arbitrary, SURVEY 8a "semantics" 2):
+    P = k (rho - rho0) magnifies a relative density difference by rho / (rho - rho0).  The engine's contract sits at 1.01 x the reference's own
+    order-induced spread; that, not 1e-4, is what a HIP-vs-literal comparison can be held to (tests/test_gpu_parity_full.py asserts 3e-4)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "settled_pool.npz"))
+    settled = fx["settled"]
+    sp = pkg.default_params()
+    sp.param_mass = float(fx["mass"])
+    op = to_oracle_params(oracle, sp)
+    end = {}
+    try:
+        for c in (0, 1, 2):
+            oracle.set_contract(c)
+            end[c] = oracle.substep(settled, op, steps=100)
+    finally:
+        oracle.set_contract(1)
+    for c in (0, 1, 2):                                      # the fixture's samples: bit for bit (regression pin of all three contracts)
+        assert end[c][::16].tobytes() == fx[f"after100_contract{c}_every16"].tobytes(), c
+    pm = end[0]["pressure"] > 0
+
+    def rel(a, b, m=None):
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(np.abs(a.astype(np.float64)), 1e-30)
+        return float(d[m].max() if m is not None else d.max())
+    d01, d02 = rel(end[0]["density"], end[1]["density"]), rel(end[0]["density"], end[2]["density"])
+    p01, p02 = rel(end[0]["pressure"], end[1]["pressure"], pm), rel(end[0]["pressure"], end[2]["pressure"], pm)
+    print("settled pool + 100 substeps: density  literal vs engine %.2e, literal vs shader-order literal %.2e; pressure %.2e, %.2e" % (d01, d02, p01, p02))
+    assert d01 <= 1e-4 and d02 <= 1e-4                       # density: north_star's tolerance holds, for the engine's contract and for the reference against itself
+    assert p02 >= 1.5e-4                                      # pressure: the reference's OWN two legal orders are 1.7e-4 apart ...
+    assert p01 <= 1.1 * p02                                   # ... and the engine's contract is no further from the literal arithmetic than that
+    assert np.allclose(fx["spread"][1, 1:5], [d01, d02, p01, p02], rtol=1e-12)
