@@ -102,7 +102,8 @@ struct SphEngine {
     int cur = 0;
     bool internalValid = false, aosValid = false, accValid = false;
     // grid / sort scratch
-    uint32_t *d_cellOf = nullptr, *d_slotOf = nullptr, *d_order = nullptr;
+    uint2* d_binKey = nullptr;              // k_bin: (cell, arrival slot inside the cell) of every state slot
+    uint32_t* d_order = nullptr;
     float4* d_stencil = nullptr;            // SetStencilTargets points (binding 5 of StencilAttract.comp)
     size_t stencilCount = 0;
     int32_t *d_llNext = nullptr, *d_llCell = nullptr, *d_llKey = nullptr;   // linked-list A/B variant (particleNext, particleCell, cellKey)
@@ -243,7 +244,7 @@ void free_particle_buffers(SphEngine* e) {
     dev_free(e->d_aos);
     for (int b = 0; b < 2; ++b) { dev_free(e->d_pos[b]); dev_free(e->d_vel[b]); dev_free(e->d_rp[b]); dev_free(e->d_foam[b]); }
     dev_free(e->d_acc);
-    dev_free(e->d_cellOf); dev_free(e->d_slotOf); dev_free(e->d_order); dev_free(e->d_tmp);
+    dev_free(e->d_binKey); dev_free(e->d_order); dev_free(e->d_tmp);
     dev_free(e->d_slabCnt); for (auto& f : e->d_face) dev_free(f);
     e->faceCap = 0; dev_free(e->d_shapeTab); dev_free(e->d_sPV); dev_free(e->d_sOwn);
     for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -270,8 +271,7 @@ int alloc_particle_buffers(SphEngine* e, size_t n) {
         if ((rc = dev_alloc(&e->d_foam[b], n))) return rc;
     }
     if ((rc = dev_alloc(&e->d_acc, n))) return rc;
-    if ((rc = dev_alloc(&e->d_cellOf, n))) return rc;
-    if ((rc = dev_alloc(&e->d_slotOf, n))) return rc;
+    if ((rc = dev_alloc(&e->d_binKey, n))) return rc;
     if ((rc = dev_alloc(&e->d_order, n))) return rc;
     if ((rc = dev_alloc(&e->d_tmp, n))) return rc;
     if ((rc = dev_alloc(&e->d_slabCnt, 16))) return rc;
@@ -355,7 +355,7 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     }
     if (n) {
         Timed t(e, SPH_K_BIN);
-        hipLaunchKernelGGL(k_bin, dim3(nb), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellCount, n,
+        hipLaunchKernelGGL(k_bin, dim3(nb), dim3(kBlock), 0, e->stream, k, e->d_pos[e->cur], e->d_binKey, e->d_cellCount, n,
                            e->slab ? e->d_slabCnt + 2 : (const uint32_t*)nullptr);
     }
     {
@@ -367,15 +367,15 @@ int build_grid(SphEngine* e, const SimK& k, bool commitLive = false) {
     }
     if (n) {
         Timed t(e, SPH_K_SCATTER);
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_vel[e->cur], e->d_cellOf, e->d_slotOf, e->d_cellStart, e->d_tmp, n,
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(kBlock), 0, e->stream, e->d_binKey, e->d_cellStart, e->d_tmp, n,
                            e->slab ? e->d_slabCnt + 2 : (const uint32_t*)nullptr);
         if (sortedCopy) {
-            hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
+            hipLaunchKernelGGL((k_rank<true>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellStart, e->d_order, n, C,
                                e->d_pos[e->cur], e->d_vel[e->cur], e->d_rp[e->cur], e->d_foam[e->cur], e->d_sPV, e->d_sOwn, k.gx, k.gy,
                                (commitLive && e->slab) ? e->d_slabCnt + 2 : (uint32_t*)nullptr);
         } else {
-            hipLaunchKernelGGL((k_rank<false>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellOf, e->d_cellStart, e->d_order, n, C,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k.gx, k.gy,
+            hipLaunchKernelGGL((k_rank<false>), dim3(nb), dim3(kBlock), 0, e->stream, e->d_tmp, e->d_cellStart, e->d_order, n, C,
+                               nullptr, e->d_vel[e->cur], nullptr, nullptr, nullptr, nullptr, k.gx, k.gy,
                                (commitLive && e->slab) ? e->d_slabCnt + 2 : (uint32_t*)nullptr);
         }
     }
@@ -829,7 +829,7 @@ static std::vector<unsigned char> graph_material(const SphEngine* e, float dt, i
                          (int)e->idBase, e->allocatedCells, 0};
     add(opts, sizeof(opts));
     const void* ptrs[20] = {e->d_aos, e->d_pos[0], e->d_pos[1], e->d_vel[0], e->d_vel[1], e->d_rp[0], e->d_rp[1], e->d_foam[0], e->d_foam[1], e->d_acc,
-                            e->d_cellOf, e->d_slotOf, e->d_order, e->d_tmp, e->d_cellCount, e->d_cellStart, e->d_blockSums, e->d_sPV, e->d_sPV, e->d_sOwn};
+                            e->d_binKey, e->d_binKey, e->d_order, e->d_tmp, e->d_cellCount, e->d_cellStart, e->d_blockSums, e->d_sPV, e->d_sPV, e->d_sOwn};
     add(ptrs, sizeof(ptrs));
     const void* more[3] = {e->d_llNext, e->d_shapeTab, e->d_stats};
     add(more, sizeof(more));

@@ -43,13 +43,23 @@ __global__ __launch_bounds__(kBlock) void k_import(const SphParticle* __restrict
     foam[i] = d.z;
 }
 
+// ---- exclusive scan over the histogram: tiles -------------------------------------------
+#ifndef SPH_SCAN_ITEMS
+#define SPH_SCAN_ITEMS 16
+#endif
+constexpr int kScanItems = SPH_SCAN_ITEMS;           // 256 threads x 16 = 4096 cells per block
+constexpr int kScanTile = kBlock * kScanItems;
+
 // ---- BuildGrid.comp:21-31: cell of every particle + histogram -------------------------
 // The state is (nearly) cell-sorted from the previous substep, so equal cells sit in adjacent
 // lanes: each run of equal cells inside a wave issues ONE returning atomic (run leader) and
 // hands out consecutive slots, instead of one contended atomic per particle.
-__global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict__ pos, uint32_t* __restrict__ cellOf,
-                                                uint32_t* __restrict__ slotOf, uint32_t* __restrict__ cellCount, int n,
-                                                const uint32_t* __restrict__ slotsInUse) {
+// Round 5: (cell, slot) leave as ONE 8-byte key.  (Also tried in round 5: this pass adding its particles to the sum of the scan tile their cell lies in,
+// to save k_scan_reduce's read of the histogram.  One global atomic per wave and tile: k_bin 31 -> 204 us; aggregated per block in LDS first, one or two
+// global atomics per block: 31 -> 77 us.  Consecutive blocks add to the SAME word at the same time, and a device-scope atomic on one address costs
+// hundreds of nanoseconds on this chip (eight L2s that are not coherent with each other): profiles/r05_grid_build.txt.)
+__global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict__ pos, uint2* __restrict__ binKey,
+                                                uint32_t* __restrict__ cellCount, int n, const uint32_t* __restrict__ slotsInUse) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // z-slab mode without host round trips: n is only a launch bound, the slots that hold data are counted on the device
@@ -64,26 +74,19 @@ __global__ __launch_bounds__(kBlock) void k_bin(SimK k, const float4* __restrict
         const int cz = cell_z_local(k, p.z);
         if (!(fbits(p.w) & F_DEAD)) cell = (uint32_t)((cz * k.gy + cy) * k.gx + cx);   // flatten(), BuildGrid.comp:19
     }
+    const unsigned long long upto = (2ull << lane) - 1ull;              // bits 0..lane
+    const bool valid = cell != 0xFFFFFFFFu;
     const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
     const bool head = (lane == 0) || (cell != prev);
     const unsigned long long heads = __ballot(head);
-    const unsigned long long upto = (2ull << lane) - 1ull;              // bits 0..lane
     const int startLane = 63 - __clzll((long long)(heads & upto));
     const unsigned long long above = heads & ~upto;
     const int endLane = above ? (__ffsll((long long)above) - 1) : 64;
     uint32_t base = 0;
-    const bool valid = cell != 0xFFFFFFFFu;
     if (head && valid) base = atomicAdd(&cellCount[cell], (uint32_t)(endLane - lane));
     base = (uint32_t)__shfl((int)base, startLane, 64);
-    if (inRange) {
-        cellOf[i] = cell;
-        slotOf[i] = base + (uint32_t)(lane - startLane);
-    }
+    if (inRange) binKey[i] = make_uint2(cell, base + (uint32_t)(lane - startLane));
 }
-
-// ---- exclusive scan over the histogram -------------------------------------------------
-constexpr int kScanItems = 16;                       // 256 threads x 16 = 4096 cells per block
-constexpr int kScanTile = kBlock * kScanItems;
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const int lane = threadIdx.x & 63;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restri
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of the per-block sums (any count, chunks of 256 with carry)
+// single block: exclusive scan of the per-tile sums (any count, chunks of 256 with carry); grids beyond kScanFusedBlocks tiles only
 __global__ __launch_bounds__(kBlock) void k_scan_blocksums(uint32_t* __restrict__ blockSums, int numBlocks) {
     __shared__ uint32_t sm[4];
     uint32_t carry = 0;
@@ -190,15 +193,16 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ cn
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) cellStart[numCells] = before + total;
 }
 
-// ---- counting-sort scatter: tmp[slot] = (particle id, source index) ---------------------
-__global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ vel, const uint32_t* __restrict__ cellOf,
-                                                    const uint32_t* __restrict__ slotOf, const uint32_t* __restrict__ cellStart,
+// ---- counting-sort scatter: tmp[slot] = (source index, cell) ------------------------------
+// (round 5: the particle id is no longer carried -- reading it cost a 16-byte vel record per particle for 4 bytes; k_rank gathers the ids of a
+//  cell's few members itself, out of cache lines it loads anyway -- and the cell rides along instead, which saves k_rank a dependent gather)
+__global__ __launch_bounds__(kBlock) void k_scatter(const uint2* __restrict__ binKey, const uint32_t* __restrict__ cellStart,
                                                     uint2* __restrict__ tmp, int n, const uint32_t* __restrict__ slotsInUse) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n || (slotsInUse && (uint32_t)i >= *slotsInUse)) return;
-    if (cellOf[i] == 0xFFFFFFFFu) return;     // dead slot (z-slab mode)
-    uint32_t dst = cellStart[cellOf[i]] + slotOf[i];
-    tmp[dst] = make_uint2(fbits(vel[i].w), (uint32_t)i);
+    const uint2 key = binKey[i];
+    if (key.x == 0xFFFFFFFFu) return;         // dead slot (z-slab mode)
+    tmp[cellStart[key.x] + key.y] = make_uint2((uint32_t)i, key.x);
 }
 
 // ---- canonical order inside each cell: rank by ascending particle id ---------------------
@@ -208,29 +212,57 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ v
 // reads (sph_pass.h SortedIn: a 32-byte record + 16 bytes of own data per particle; 1/rho is the one correctly rounded division per
 // neighbour of the numerics contract, item 9).
 template <bool COPY>
-__global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellOf,
-                                                 const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells,
+__global__ __launch_bounds__(kBlock) void k_rank(const uint2* __restrict__ tmp, const uint32_t* __restrict__ cellStart, uint32_t* __restrict__ order, int n, int numCells,
                                                  const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                  const float2* __restrict__ rp, const float* __restrict__ foam,
                                                  float4* __restrict__ pv, float4* __restrict__ own, int gx, int gy,
                                                  uint32_t* __restrict__ liveOut) {
-    int d = blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.x * kBlock + threadIdx.x;
     // z-slab mode: the sorted output will hold exactly the live particles; their count replaces the slots-in-use count
     // of the exchange (k_bin / k_scatter, which read that count, have finished)
-    if (d == 0 && liveOut) *liveOut = cellStart[numCells];
-    if (d >= n || (uint32_t)d >= cellStart[numCells]) return;   // live particles only (cellStart[numCells] <= n)
-    uint2 me = tmp[d];
-    // everything that depends only on the source index is requested NOW, beside the cell lookups below (one level of
-    // dependent memory latency less than gathering after the rank is known)
-    float4 P = make_float4(0.0f, 0.0f, 0.0f, 0.0f), V = P;
+    const uint32_t nLive = cellStart[numCells];                  // (<= n)
+    if (d == 0 && liveOut) *liveOut = nLive;
+    if ((uint32_t)(blockIdx.x * kBlock) >= nLive) return;        // whole block beyond the live particles
+    const bool act = d < n && (uint32_t)d < nLive;               // every lane of a wave stays to the end: the ids cross the lanes below
+    const uint2 me = act ? tmp[d] : make_uint2(0u, 0u);          // (source index, cell)
+    // everything that depends only on the source index is requested NOW, beside the cell lookups below
+    float4 V = make_float4(0.0f, 0.0f, 0.0f, 0.0f), P = V;
     float2 RP = make_float2(0.0f, 0.0f);
     float F = 0.0f;
-    if (COPY) { P = pos[me.y]; V = vel[me.y]; RP = rp[me.y]; F = foam[me.y]; }
-    uint32_t c = cellOf[me.y];
-    uint32_t s = cellStart[c], e = cellStart[c + 1];
+    if (act) {
+        V = vel[me.x];
+        if (COPY) { P = pos[me.x]; RP = rp[me.x]; F = foam[me.x]; }
+    }
+    const uint32_t c = me.y;
+    const uint32_t s = act ? cellStart[c] : 0u, e = act ? cellStart[c + 1] : 0u;
+    const uint32_t myId = fbits(V.w);
     uint32_t rank = 0;
-    for (uint32_t q = s; q < e; ++q) rank += (tmp[q].x < me.x) ? 1u : 0u;
-    order[s + rank] = me.y;
+    // The ids of the cell's other members: a cell's slots are consecutive, i.e. its members are NEIGHBOURING LANES of this wave, and every lane
+    // holds its particle's id in V.w already -- a cross-lane read, no memory access.  Only members outside the wave's 64 slots (a cell that
+    // straddles the wave's edge, a crowded cell of compressed fluid) are gathered from memory.
+    const uint32_t d0 = (uint32_t)d - (uint32_t)(threadIdx.x & 63);                // slot of lane 0
+    const uint32_t m = e - s;
+    uint32_t mWave = m;
+    for (int sh = 32; sh >= 1; sh >>= 1) mWave = max(mWave, (uint32_t)__shfl_xor((int)mWave, sh, 64));
+    if (mWave > 1u) {                                                              // wave-uniform
+        if (mWave <= 64u) {
+            for (uint32_t j = 0; j < mWave; ++j) {                                 // wave-uniform trip count: the shuffle needs every lane
+                const uint32_t src = s + j - d0;                                   // (a member in front of the wave wraps to a huge number)
+                const uint32_t idq = (uint32_t)__shfl((int)myId, (int)(src & 63u), 64);
+                rank += (j < m && src < 64u && idq < myId) ? 1u : 0u;
+            }
+        } else {                                                                   // a cell larger than a wave somewhere in it: every lane against every lane
+            for (uint32_t L = 0; L < 64u; ++L) {
+                const uint32_t idq = (uint32_t)__shfl((int)myId, (int)L, 64);
+                const uint32_t q = d0 + L;
+                rank += (q >= s && q < e && idq < myId) ? 1u : 0u;
+            }
+        }
+        for (uint32_t q = s; q < min(e, d0); ++q) rank += (fbits(vel[tmp[q].x].w) < myId) ? 1u : 0u;             // members in front of the wave's first slot
+        for (uint32_t q = max(s, d0 + 64u); q < e; ++q) rank += (fbits(vel[tmp[q].x].w) < myId) ? 1u : 0u;       // ... and behind its last one
+    }
+    if (!act) return;
+    if (!COPY || (fbits(P.w) & F_GHOST1)) order[s + rank] = me.x;                  // (read only for ghosts: special_slot passes an inactive ghost's density through)
     if (COPY) {
         pv[2u * (s + rank)] = make_float4(P.x, P.y, P.z, RP.x > 0.0f ? 1.0f / RP.x : 0.0f);
         pv[2u * (s + rank) + 1u] = make_float4(V.x, V.y, V.z, RP.y);

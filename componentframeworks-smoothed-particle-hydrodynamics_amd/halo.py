@@ -101,7 +101,9 @@ class HipSlabEngine:
         _eng._check(self._L.sph_slab_unpack_async(self._h, recv_lo_ptr, recv_hi_ptr, int(recv_cap)))
 
     def exchange(self, comm: "RcclComm"):
-        """pack -> grouped ncclSend/ncclRecv with the z-neighbours -> unpack, on the engine's stream (sph_slab_exchange)."""
+        """pack -> grouped ncclSend/ncclRecv with the z-neighbours -> unpack, on the engine's stream (sph_slab_exchange).  The engine gets the
+        members first, as dispatch() and step_begin() do: the exchange cuts its records for the grid the NEXT dispatch will use."""
+        _eng._check(self._L.sph_set_params(self._h, C.byref(self._p)))
         _eng._check(self._L.sph_slab_exchange(self._h, comm._h))
 
     # -- boundary-first substep: the exchange of the next substep beside the interior of the SPH pass ----------

@@ -355,7 +355,7 @@ def test_random_call_sequences_on_z_slabs(pkg, oracle, seed):
         k = int(rng.integers(0, world))
         kind = rng.choice(["kick", "member"])
         if kind == "kick":
-            grp.sims[k].engine.apply_wave_impulse(60.0, 2.0, 0.5, (0.0, 0.3, 1.0), -1e9, 1e9)
+            grp.sims[k].engine.apply_wave_impulse(400.0 * float(sp.param_h), 2.0, 0.5, (0.0, 0.3, 1.0), -1e9, 1e9)   # (strong against h: a kick that holds whole faces)
         else:
             q = type(sp).from_buffer_copy(sp)
             q.param_gasConstant = float(sp.param_gasConstant) * 1.5
