@@ -45,9 +45,9 @@ __global__ __launch_bounds__(kBlock) void k_import(const SphParticle* __restrict
 
 // ---- exclusive scan over the histogram: tiles -------------------------------------------
 #ifndef SPH_SCAN_ITEMS
-#define SPH_SCAN_ITEMS 16
+#define SPH_SCAN_ITEMS 8     // (16: scan 16.8 us at config 3, 8: 14.4 us -- twice the blocks for the same bytes; gpurun_out/r05 A/B, profiles/r05_grid_build.txt)
 #endif
-constexpr int kScanItems = SPH_SCAN_ITEMS;           // 256 threads x 16 = 4096 cells per block
+constexpr int kScanItems = SPH_SCAN_ITEMS;           // 256 threads x 8 = 2048 cells per block
 constexpr int kScanTile = kBlock * kScanItems;
 
 // ---- BuildGrid.comp:21-31: cell of every particle + histogram -------------------------
@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sm, ui
     return base + inc - v;
 }
 
-// Each thread owns kScanItems CONSECUTIVE cells (four 16-byte loads), so a 4096-cell tile needs one block-wide scan.
+// Each thread owns kScanItems CONSECUTIVE cells (16-byte loads), so a tile of 256 x kScanItems cells needs one block-wide scan.
 __device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, int c0, int numCells, uint32_t (&v)[kScanItems]) {
     if (c0 + kScanItems <= numCells) {
         const uint4* p = reinterpret_cast<const uint4*>(cnt + c0);
