@@ -402,18 +402,18 @@ def main():
     achieved = alg_bytes / sph_avg_s / 1e9 if sph_avg_s > 0 else 0.0
     # HBM traffic, VALU instruction counts and L1 cache-line accesses are NOT measured in this run: they come from separate
     # rocprofv3 --pmc passes over this same command (tools/profile_bench.sh), summarised for exactly the timed launches in
-    # profiles/r04_bench_counters.json.  That file carries the hash of the engine sources it was measured on; a file from
+    # profiles/r05_bench_counters.json.  That file carries the hash of the engine sources it was measured on; a file from
     # other sources is refused (traffic stays null and traffic_source says why).
     traffic = traffic_source = None
     valu = None
-    cpath = os.path.join(ROOT, "profiles", "r04_bench_counters.json")
+    cpath = os.path.join(ROOT, "profiles", "r05_bench_counters.json")
     kname = "k_sph_ll" if args.grid_build == "ll" else (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor]
     if os.path.exists(cpath) and not multi:
         try:
             cj = json.load(open(cpath))
             here = pkg.build.csrc_hash()
             if cj.get("csrc_hash") != here:
-                traffic_source = f"profiles/r04_bench_counters.json was measured on other engine sources ({cj.get('csrc_hash')} != {here}): not used"
+                traffic_source = f"profiles/r05_bench_counters.json was measured on other engine sources ({cj.get('csrc_hash')} != {here}): not used"
             elif cj.get("workload") == wl and cj.get("kernel") == kname:
                 traffic = cj.get("hbm_bytes_per_launch")
                 traffic_source = cj.get("source")
@@ -426,7 +426,7 @@ def main():
                             "tcp_line_accesses_per_cycle_per_cu_at_2GHz": (cj["tcp_line_accesses_per_launch"] / 256.0 / (sph_avg_s * 2.0e9)) if cj.get("tcp_line_accesses_per_launch") else None,
                             "source": cj.get("source")}
         except Exception as ex:                              # noqa: BLE001
-            traffic, traffic_source = None, f"profiles/r04_bench_counters.json unreadable: {ex}"
+            traffic, traffic_source = None, f"profiles/r05_bench_counters.json unreadable: {ex}"
 
     out = {
         "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed, "unit": "particle-substeps/s",
@@ -449,7 +449,7 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
             "window": {"kernel": kname, "first_launch": args.warmup, "launches": int(sph_launches),
-                       "note": "0-based index among this kernel's launches of the run; profiles/r04_bench_kernel_window.json holds the rocprofv3 --kernel-trace average of exactly these launches"},
+                       "note": "0-based index among this kernel's launches of the run; profiles/r05_bench_kernel_window.json holds the rocprofv3 --kernel-trace average of exactly these launches"},
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sph_avg_s * 1e6, "launches_timed": int(sph_launches),
             # the same window with the 80-byte records updated by EVERY substep (what the 164 N figure prices; aos_eager below)
             "frac_records_updated_every_substep": (alg_bytes / (aos_eager["sph_pass_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if aos_eager and aos_eager.get("sph_pass_us") else None,
