@@ -1653,7 +1653,14 @@ Rccl g_rccl;
 int rccl_load() {
     if (g_rccl.lib) return SPH_OK;
     void* h = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    // SPH_RCCL_LIBRARY names the library that provides the nccl* entry points (default: librccl.so.1).  The tests put a stand-in there that moves the messages
+    // between PROCESSES ON ONE GPU through shared memory and REFUSES a receive whose size differs from its send's (tests/fake_rccl/): the engine's own multi-rank
+    // code -- plans, grouped face messages, unpack -- then runs between real ranks on a one-GPU box, where RCCL itself refuses two ranks on one device.
+    if (const char* over = std::getenv("SPH_RCCL_LIBRARY")) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(SPH_ERR_HIP, "SPH_RCCL_LIBRARY=%s cannot be loaded: %s", over, dlerror());
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { if (h) break; h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); }
     if (!h) return fail(SPH_ERR_HIP, "RCCL not available: %s", dlerror());
     Rccl r;
     r.lib = h;

@@ -333,6 +333,9 @@ int sph_slab_message_bytes(SphEngine* e, uint64_t out[4]);
 int sph_slab_message_records(uint32_t seen, uint32_t before, uint32_t cap);
 /* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy: rank 0 creates the id and hands its 128 bytes to the other ranks
  * by any means (MPI, a file, torch.distributed); one rank per process, on the current HIP device. */
+/* The nccl* entry points are loaded with dlopen ("librccl.so.1"); the environment variable SPH_RCCL_LIBRARY names another library to load them from.  The tests use
+ * it to put a stand-in transport in RCCL's place that runs between processes on ONE GPU and refuses a receive whose size differs from its send's
+ * (tests/fake_rccl/fake_rccl.c, tests/test_gpu_fake_rccl.py). */
 int sph_comm_unique_id(void* out128);
 int sph_comm_create(SphComm** out, const void* id128, int rank, int world);
 int sph_comm_destroy(SphComm* comm);
