@@ -120,6 +120,10 @@ def main():
     # SPH_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share
     # devices, halo records are staged through the host); the measured configuration is nccl = RCCL.
     backend = os.environ.get("SPH_BENCH_BACKEND", "nccl")
+    # The ENGINE's transport (sph_slab_exchange / sph_slab_step_finish behind the C-ABI) is RCCL whenever torch's is; with SPH_RCCL_LIBRARY naming a stand-in
+    # for librccl (tests/fake_rccl/: messages between processes on ONE GPU through shared memory) the engine's RCCL code path also runs in a gloo rehearsal --
+    # the driver's exact N > 1 loop, minus xGMI (tests/test_gpu_fake_rccl.py::test_bench_two_ranks_engine_path_over_the_stand_in_transport).
+    engine_rccl = backend == "nccl" or bool(os.environ.get("SPH_RCCL_LIBRARY"))
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -165,8 +169,8 @@ def main():
         sim = pkg.SPHFluidGPU.from_particles(rec, sp, stream=stream)
         n_local, n_total = len(rec), len(rec)
     else:
-        sim = halo.SlabSimulation.from_config(cfg, sp, rank, world, stream=stream, transport="rccl" if backend == "nccl" else "host")
-        if backend == "nccl":
+        sim = halo.SlabSimulation.from_config(cfg, sp, rank, world, stream=stream, transport="rccl" if engine_rccl else "host")
+        if engine_rccl:
             sim.engine.set_deadline(args.deadline)     # every wait for a neighbour is bounded: a rank that is stuck says so and exits non-zero
         rec = None
         n_local, n_total = sim.num_owned(), cfg.n
@@ -189,7 +193,7 @@ def main():
         print(json.dumps({"bench_failed": True, "rank": rank, "world": world, "where": where, "substeps_issued": wave["n"], "error": str(ex), "plan": plan}), file=sys.stderr, flush=True)
         os._exit(3)
 
-    slab_rccl = multi and backend == "nccl"
+    slab_rccl = multi and engine_rccl
 
     def barrier():
         if slab_rccl:                              # never a blind wait: the engine's streams are polled against the deadline first
@@ -236,7 +240,7 @@ def main():
     # to itself: the only send / receive a one-GPU box can execute; on a node it still says that RCCL moves bytes on this rank)
     selftest_gbs = None
     selftest_faces_ms = None
-    if multi and backend == "nccl" and isinstance(sim.exchange, halo.RcclComm):
+    if multi and engine_rccl and isinstance(sim.exchange, halo.RcclComm):
         try:
             sim.exchange.selftest_gbs(1 << 20)
             selftest_gbs = round(sim.exchange.selftest_gbs(int(sim.engine.message_bytes()[2] or sim.engine.message_bytes()[3] or (1 << 24)) & ~3), 1)
@@ -340,7 +344,7 @@ def main():
     # exchange stream and on the engine's stream): pack -> transfer -> unpack, the end of the exchange and the end of the pass measured from
     # the step's start.  The transfer was hidden behind the interior iff exchange_end <= pass_end; sent bytes / transfer ms = the link's rate.
     exchange_diag = None
-    if multi and backend == "nccl" and isinstance(sim.exchange, halo.RcclComm) and getattr(sim, "overlap", False):
+    if multi and engine_rccl and isinstance(sim.exchange, halo.RcclComm) and getattr(sim, "overlap", False):
         sim.set_option(pkg.SPH_OPT_TIMING, 1)
         acc = [0.0] * 5
         nd = 5
@@ -356,7 +360,7 @@ def main():
         except pkg.SphError:
             hs_ms = 0.0
         mine = acc + [float(v) for v in mb] + [float(hs_ms)]
-        tst = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        tst = torch.tensor(mine, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         gathered = [torch.zeros_like(tst) for _ in range(world)]
         dist.all_gather(gathered, tst)
         exchange_diag = {"per_rank": [{"pack_ms": round(g[0].item(), 4), "transfer_ms": round(g[1].item(), 4), "unpack_ms": round(g[2].item(), 4),
@@ -435,7 +439,7 @@ def main():
         "config": {
             "workload": f"{wl}: {base.n} particles and a {gx}x{gy}x{gz}-cell grid per GPU (BASELINE.json configs[{base.index - 1}]"
                         + (f", weak-scaled along z to {args.gpus} slabs" if multi else "") + ")"
-                        + ("" if backend == "nccl" else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]"),
+                        + ("" if backend == "nccl" else (f" [REHEARSAL over {backend}, the engine's RCCL path over a stand-in transport: not a measurement]" if engine_rccl else f" [REHEARSAL over {backend}, host-staged halos: not a measurement]")),
                         # (--slab-path with one rank: the same code path, a communicator of one, no neighbour to exchange with)
             "particles": n_total, "grid": list(cfg.grid), "h": 0.28, "dt": 1e-3, "spacing_over_h": base.spacing_factor,
             "neighbor_kernel": (None, "k_sph_slow", "k_sph_list", "k_sph_walk")[args.neighbor],

@@ -174,3 +174,31 @@ def test_a_rank_that_stops_calling_is_an_error_on_its_neighbour_not_a_hang(pkg, 
     assert rc1 == 0 and "LEAVING" in so1
     assert rc0 == 7 and "SPHERROR" in so0, so0[-1500:] + se0[-2000:]
     assert time.time() - t0 < 120
+
+
+def test_bench_two_ranks_engine_path_over_the_stand_in_transport(fake_lib):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), on this one GPU: torch's process group over gloo, the
+    ENGINE's transport = its RCCL code path over the stand-in library (SPH_RCCL_LIBRARY).  The loop that is timed on a node -- SlabSimulation.from_config
+    (transport "rccl"), priming exchange, boundary-first steps with the plans' handshake, the self-tests, the exchange diagnostics, the status gather --
+    runs between two real ranks and prints its one line."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SPH_BENCH_BACKEND="gloo", SPH_RCCL_LIBRARY=fake_lib, FAKE_RCCL_TIMEOUT_S="30", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config2", "--steps", "8",
+           "--warmup", "3", "--no-cpu-baseline", "--deadline", "60"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert "stand-in transport" in d["config"]["workload"]
+    assert d["slab_status"]["overflow_on_any_rank"] is False
+    ex = d["exchange"]
+    assert ex is not None and len(ex["per_rank"]) == 2 and ex["rccl_selftest_faces_ms"] is not None
+    sent = [r["sent_bytes_lo_hi"] for r in ex["per_rank"]]
+    assert sent[0][0] == 0 and sent[0][1] > 0 and sent[1][0] > 0 and sent[1][1] == 0          # each rank has one neighbour, and bytes went out
