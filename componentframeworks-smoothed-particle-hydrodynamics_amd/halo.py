@@ -408,6 +408,17 @@ class SlabSimulation:
     def set_option(self, option, value):
         self.engine.set_option(option, value)
 
+    def set_deadline(self, seconds: float):
+        """Limit of every wait for a neighbour rank (the plans' handshake of an exchange, sync(deadline=...)): SphError (SPH_ERR_TIMEOUT) instead of a hang."""
+        self.engine.set_deadline(seconds)
+        self._deadline = float(seconds)
+
+    def sync(self, deadline=None):
+        """Drain this rank's streams; with a deadline (default: the one set by set_deadline) the streams are polled and a transfer whose neighbour never
+        posted its half raises instead of blocking for ever -- print the error and end the process."""
+        d = deadline if deadline is not None else getattr(self, "_deadline", None)
+        self.engine.sync(deadline=d)
+
     def kernel_times(self, reset=False):
         return self.engine.kernel_times(reset)
 
